@@ -1,0 +1,205 @@
+/*
+ * mdt_hip.h — C ABI of the MI355X-native (gfx950) mDT hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers / sizes / a HIP stream
+ * (as `void*` = hipStream_t) and NO torch types.  The caller owns every buffer,
+ * workspace included; the library allocates nothing, keeps no global state besides
+ * a thread-local error string, never synchronises the host and is re-entrant, so
+ * forward and backward may run on different host threads and any call sequence can
+ * be captured in a hipGraph.
+ *
+ * Return value: 0 on success, a negative mdt_status otherwise; the message is
+ * available through mdt_last_error_string() on the calling thread.
+ *
+ * The reference has no native boundary for this path (it is eager PyTorch); each
+ * function cites the reference operator sequence it replaces (paths relative to
+ * /root/reference/mDT/src).  INTEGRATION.md shows the reference-side binding.
+ */
+#ifndef MDT_HIP_H
+#define MDT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDT_ABI_VERSION 1
+
+typedef enum { MDT_F32 = 0, MDT_BF16 = 1 } mdt_dtype;
+
+typedef enum {
+  MDT_OK = 0,
+  MDT_ERR_ARG = -1,          /* shape / alignment / null-pointer contract violated */
+  MDT_ERR_UNSUPPORTED = -2,  /* valid request this build has no kernel for */
+  MDT_ERR_LAUNCH = -3        /* hipLaunch / hipMemsetAsync reported an error */
+} mdt_status;
+
+/* GEMM epilogue selector (bit flags) */
+enum {
+  MDT_EPI_BIAS = 1,      /* + bias[n] */
+  MDT_EPI_GELU = 2,      /* erf-GELU; if aux != NULL the pre-activation is stored there */
+  MDT_EPI_RESIDUAL = 4,  /* + residual[m, n] */
+  MDT_EPI_DGELU = 8,     /* * gelu'(aux[m, n]) (backward of MDT_EPI_GELU) */
+  MDT_EPI_ACCUM = 16,    /* C += result (plain read-modify-write, fp32 or T) */
+  MDT_EPI_ATOMIC = 32    /* C (fp32) += result with float atomics (split-K weight gradients) */
+};
+
+int mdt_abi_version(void);
+const char* mdt_last_error_string(void);
+
+/* ------------------------------------------------------------------ GEMM
+ * C[M,N] = epilogue( alpha * op(A)[M,K] @ op(B)[K,N] )
+ *   trans_a = 0: A stored [M,K] (lda = row stride);  1: stored [K,M]
+ *   trans_b = 0: B stored [N,K] (nn.Linear weight, y = x W^T);  1: stored [K,N]
+ * Replaces nn.Linear forward and its autograd (modules/multihead_attention.py:134-137,203;
+ * modules/graphormer_graph_encoder_layer.py:135-137; HF BertLayer/ViTLayer dense layers
+ * called from modules/multi_graphormer_fusion_layer.py:94-96,138-146).
+ * dtype: element type of A, B, bias, residual, aux.  out_dtype: element type of C.
+ * split_k > 1 requires MDT_EPI_ATOMIC and a pre-zeroed (or accumulating) fp32 C.
+ */
+int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int trans_b,
+             int64_t M, int64_t N, int64_t K,
+             const void* A, int64_t lda, const void* B, int64_t ldb,
+             void* C, int64_t ldc, int epilogue, float alpha,
+             const void* bias, const void* residual, int64_t ldr,
+             void* aux, int64_t ldaux, int split_k);
+
+/* Column sums: out[n] (+)= sum_m X[m,n]  (bias gradients).  out is fp32, accumulated
+ * with atomics — zero it first unless accumulating. */
+int mdt_colsum(void* stream, int dtype, int64_t M, int64_t N, const void* X, int64_t ldx, float* out);
+
+/* ------------------------------------------------------------------ LayerNorm
+ * y = (x - mean) * rstd * gamma + beta, rows of width D (fairseq LayerNorm eps 1e-5,
+ * HF LayerNorm eps 1e-12: modules/graphormer_graph_encoder_layer.py:127-130,138-141;
+ * modules/multigraphormer_graph_encoder.py:400-403).  mean / rstd are fp32 [rows].
+ */
+int mdt_layernorm_fwd(void* stream, int dtype, int64_t rows, int D, const void* x, int64_t ldx,
+                      const void* gamma, const void* beta, float eps,
+                      void* y, int64_t ldy, float* mean, float* rstd);
+/* dx = LN'(dy) (+ add[m,:] if add != NULL);  dgamma/dbeta fp32, atomically accumulated. */
+int mdt_layernorm_bwd(void* stream, int dtype, int64_t rows, int D, const void* dy, int64_t lddy,
+                      const void* x, int64_t ldx, const void* gamma, const float* mean, const float* rstd,
+                      const void* add, int64_t ldadd, void* dx, int64_t lddx, float* dgamma, float* dbeta);
+
+/* ------------------------------------------------------------------ attention
+ * Self-attention over `nseq` independent sequences of `S` tokens, `H` heads of `hd`,
+ * q|k|v packed per token: qkv[row, 0:D | D:2D | 2D:3D], D = H*hd.  Row of token p of
+ * sequence s = s*seq_stride + p*pos_stride (so batch-major and fairseq's time-major
+ * [T,B,C] layouts need no copy).  scores = scale * q.k + bias, softmax in fp32,
+ * out[row, h*hd:(h+1)*hd] = P @ v.  lse[s,h,p] (fp32) is saved for backward.
+ *
+ * Bias / mask sources, all optional (NULL):
+ *   key_mask   u8[nseq,S]   1 = key may be attended (HF additive mask, quirk 9 of
+ *                           −65504 / finfo.min ≡ excluded)
+ *   dense_bias f32[nseq,H,S,S]   additive (modules/multihead_attention.py:173-174)
+ *   structural (modules/graphormer_layers.py:86-110 fused, never materialised):
+ *     attn_bias f32[nseq,S,S] (added TWICE, :93 and :108), spatial_pos i32[nseq,S-1,S-1],
+ *     sp_table T[num_spatial,H], virt T[H] (graph-token virtual distance)
+ *   key_pad    u8[nseq,S]   1 = padded key → −inf (multihead_attention.py:180-187)
+ */
+typedef struct {
+  int dtype;
+  int nseq, S, H, hd;
+  int64_t seq_stride, pos_stride; /* in rows */
+  float scale;
+  const void* qkv; int64_t ld_qkv;
+  void* out; int64_t ld_out;
+  float* lse;
+  const uint8_t* key_mask;
+  const float* dense_bias;
+  const float* attn_bias;
+  const int32_t* spatial_pos;
+  const void* sp_table;
+  const void* virt;
+  const uint8_t* key_pad;
+  int num_spatial;
+} mdt_attn_fwd_args;
+int mdt_attention_fwd(void* stream, const mdt_attn_fwd_args* a);
+
+typedef struct {
+  mdt_attn_fwd_args f;        /* same tensors as forward (out = forward output, lse filled) */
+  const void* dout; int64_t ld_dout;
+  void* dqkv; int64_t ld_dqkv;
+  float* d_dense_bias;        /* f32[nseq,H,S,S] or NULL */
+  float* d_sp_table;          /* f32[num_spatial,H], atomically accumulated, or NULL */
+  float* d_virt;              /* f32[H], atomically accumulated, or NULL */
+} mdt_attn_bwd_args;
+int mdt_attention_bwd(void* stream, const mdt_attn_bwd_args* a);
+
+/* Materialise the [nseq,H,S,S] structural bias (API parity with GraphAttnBias.forward,
+ * modules/graphormer_layers.py:86-110); the fused encoder path never calls this. */
+int mdt_graph_attn_bias(void* stream, int dtype, int nseq, int S, int H, const float* attn_bias,
+                        const int32_t* spatial_pos, const void* sp_table, const void* virt,
+                        float* out);
+
+/* ------------------------------------------------------------------ row movers
+ * dst[di(r), :] = alpha * a[ai(r), :] + beta * b[bi(r), :] (+ dst if accumulate)
+ * for r in [0, nrows); an index array may be NULL (identity) and then the matching
+ * stride is applied: row = r*stride + offset.  This one kernel is the bottleneck-token
+ * exchange between the text, image and graph token spaces
+ * (modules/multigraphormer_graph_encoder.py:339,363-371,425,435;
+ *  modules/multi_graphormer_fusion_layer.py:37-66) on precomputed CSR indices — the
+ * reference's boolean-mask indexing (implicit nonzero + host sync) is gone.
+ */
+int mdt_row_axpby(void* stream, int dtype, int64_t nrows, int D,
+                  void* dst, int64_t ldd, const int32_t* di, int64_t d_stride, int64_t d_off,
+                  const void* a, int64_t lda, const int32_t* ai, int64_t a_stride, int64_t a_off, float alpha,
+                  const void* b, int64_t ldb, const int32_t* bi, int64_t b_stride, int64_t b_off, float beta,
+                  int accumulate);
+/* fp32 table[idx[r], :] += src[r, :]  (embedding backward; atomics).  idx < 0 skipped. */
+int mdt_row_scatter_add_f32(void* stream, int dtype, int64_t nrows, int D, float* table, int64_t ldt,
+                            const int32_t* idx, const void* src, int64_t lds, int64_t s_stride, int64_t s_off);
+
+/* BERT embeddings: out[r,:] = word[ids[r]] + pos[r % L] + type[types[r]]  (pre-LayerNorm sum;
+ * HF BertEmbeddings, call site modules/multigraphormer_graph_encoder.py:325-329).
+ * Row r of the [M, L] id matrix goes to out row (r / L) * out_seq_stride + out_off + r % L. */
+int mdt_bert_embed_sum(void* stream, int dtype, int64_t M, int L, const int32_t* ids, const int32_t* types,
+                       const void* word, const void* pos, const void* type, int D,
+                       void* out, int64_t ldo, int64_t out_seq_stride, int64_t out_off);
+
+/* ViT patch gather (Conv2d k=s=p is a pure re-index, modules/multigraphormer_graph_encoder.py:333):
+ * cols[(i*np + py*gw + px), c*p*p + dy*p + dx] = img[i, c, py*p+dy, px*p+dx]  (img fp32 → T). */
+int mdt_vit_patchify(void* stream, int dtype, int I, int C, int HW, int p, const float* img, void* cols, int64_t ldc);
+/* tokens[i, off + 0] = cls + pos[0]; tokens[i, off + 1 + j] = patches[i*np + j] + pos[1 + j]. */
+int mdt_vit_assemble(void* stream, int dtype, int I, int np, int D, const void* patches, int64_t ldp,
+                     const void* cls, const void* pos, void* tokens, int64_t ldt, int64_t seq_stride, int64_t off);
+
+/* Graph node features (modules/graphormer_layers.py:39-50) on the padded [B, T] grid:
+ * x[b,0] = graph_token; x[b,1+n] = (node_row[b,n] >= 0 ? src[node_row[b,n]] : 0)
+ *                                  + in_emb[deg[b,n]] + out_emb[deg[b,n]]. */
+int mdt_graph_node_feature(void* stream, int dtype, int B, int T, int D, const void* src, int64_t lds,
+                           const int32_t* node_row, const int32_t* degree, const void* in_emb,
+                           const void* out_emb, const void* graph_token, void* x, int64_t ldx);
+
+/* Head tail (models/multi_modal_discussion_transformer.py:265-274): logits[m, c] =
+ * 0.5 * (cls(pooled_text[m]) + cls(pooled_bn[m])), pooled = tanh(pre-activation) given. */
+int mdt_tanh_fwd(void* stream, int dtype, int64_t n, const void* x, void* y);
+int mdt_tanh_bwd(void* stream, int dtype, int64_t n, const void* y, const void* dy, void* dx);
+
+/* Weighted 2-class cross entropy in fp16 arithmetic + counters
+ * (criterions/hatespeech_loss.py:95-118, quirk 14): logits T[M,2] gathered by rows[r];
+ * out_loss f32[1] (sum), counters i32[4] = ncorrect, num_positive_correct, total_positive,
+ * num_pred_positive; dlogits T[M,2] (zero for unlabelled rows) scaled by grad_scale. */
+int mdt_node_ce(void* stream, int dtype, int64_t M, int nlab, const void* logits, const int32_t* rows,
+                const int32_t* targets, float w_neg, float w_pos, int fp16_loss, float grad_scale,
+                float* out_loss, int32_t* counters, void* dlogits);
+
+/* Elementwise cast / transpose helpers for the bf16 weight shadow copies. */
+int mdt_cast(void* stream, int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst);
+int mdt_transpose2d(void* stream, int src_dtype, int dst_dtype, int64_t rows, int64_t cols,
+                    const void* src, int64_t lds, void* dst, int64_t ldd);
+
+/* ------------------------------------------------------------------ packer (host, C++)
+ * Native replacement of preprocess_item + collator (data/pyg_datasets/pre_processing.py:18-69,
+ * data/collator.py:69-179): integer tensors are bit-exact with the reference.
+ * All outputs are caller-allocated (pinned) host buffers sized for B x nmax.
+ */
+int mdt_pack_structure(int B, const int64_t* n_nodes, const int64_t* const* parents, int nmax,
+                       int spatial_pos_max, float* attn_bias /*[B,nmax+1,nmax+1]*/,
+                       int32_t* spatial_pos /*[B,nmax,nmax]*/, int64_t* in_degree /*[B,nmax]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDT_HIP_H */

@@ -1,0 +1,113 @@
+"""ctypes binding of libmdt_hip.so (the C ABI in include/mdt_hip.h).
+
+The library is the product: there is no Python / eager fallback.  Importing this module
+on a machine where the shared object is missing raises; calling an op with CPU tensors
+raises.  PyTorch only provides device memory and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdt_hip.so")
+
+MDT_F32, MDT_BF16 = 0, 1
+EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_ACCUM, EPI_ATOMIC = 1, 2, 4, 8, 16, 32
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class AttnFwdArgs(C.Structure):
+    _fields_ = [
+        ("dtype", _i), ("nseq", _i), ("S", _i), ("H", _i), ("hd", _i),
+        ("seq_stride", _i64), ("pos_stride", _i64), ("scale", _f),
+        ("qkv", _vp), ("ld_qkv", _i64), ("out", _vp), ("ld_out", _i64), ("lse", _vp),
+        ("key_mask", _vp), ("dense_bias", _vp), ("attn_bias", _vp), ("spatial_pos", _vp),
+        ("sp_table", _vp), ("virt", _vp), ("key_pad", _vp), ("num_spatial", _i),
+    ]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [
+        ("f", AttnFwdArgs), ("dout", _vp), ("ld_dout", _i64), ("dqkv", _vp), ("ld_dqkv", _i64),
+        ("d_dense_bias", _vp), ("d_sp_table", _vp), ("d_virt", _vp),
+    ]
+
+
+_SIGS = {
+    "mdt_abi_version": ([], _i),
+    "mdt_last_error_string": ([], C.c_char_p),
+    "mdt_gemm": ([_vp, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _f, _vp, _vp, _i64,
+                  _vp, _i64, _i], _i),
+    "mdt_colsum": ([_vp, _i, _i64, _i64, _vp, _i64, _vp], _i),
+    "mdt_layernorm_fwd": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _vp, _f, _vp, _i64, _vp, _vp], _i),
+    "mdt_layernorm_bwd": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp], _i),
+    "mdt_attention_fwd": ([_vp, C.POINTER(AttnFwdArgs)], _i),
+    "mdt_attention_bwd": ([_vp, C.POINTER(AttnBwdArgs)], _i),
+    "mdt_graph_attn_bias": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
+    "mdt_row_axpby": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _f,
+                       _vp, _i64, _vp, _i64, _i64, _f, _i], _i),
+    "mdt_row_scatter_add_f32": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _vp, _i64, _i64, _i64], _i),
+    "mdt_bert_embed_sum": ([_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i64], _i),
+    "mdt_vit_patchify": ([_vp, _i, _i, _i, _i, _i, _vp, _vp, _i64], _i),
+    "mdt_vit_assemble": ([_vp, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64], _i),
+    "mdt_graph_node_feature": ([_vp, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64], _i),
+    "mdt_tanh_fwd": ([_vp, _i, _i64, _vp, _vp], _i),
+    "mdt_tanh_bwd": ([_vp, _i, _i64, _vp, _vp, _vp], _i),
+    "mdt_node_ce": ([_vp, _i, _i64, _i, _vp, _vp, _vp, _f, _f, _i, _f, _vp, _vp, _vp], _i),
+    "mdt_cast": ([_vp, _i, _i, _i64, _vp, _vp], _i),
+    "mdt_transpose2d": ([_vp, _i, _i, _i64, _i64, _vp, _i64, _vp, _i64], _i),
+    "mdt_pack_structure": ([_i, _vp, _vp, _i, _i, _vp, _vp, _vp], _i),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+class MdtError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is the product path and has no fallback. "
+            "Build it with `python -m multimodaldiscussiontransformer_amd.build` (hipcc, gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (args, res) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    if lib.mdt_abi_version() != 1:
+        raise ImportError("libmdt_hip.so ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        raise MdtError(f"{what}: status {status}: {lib.mdt_last_error_string().decode()}")
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return MDT_F32
+    if t.dtype == torch.bfloat16:
+        return MDT_BF16
+    raise MdtError(f"unsupported dtype {t.dtype} (fp32 and bf16 only)")
+
+
+def ptr(t) -> int:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MdtError("libmdt_hip operates on device tensors only (no CPU path)")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

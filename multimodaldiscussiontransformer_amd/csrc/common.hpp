@@ -1,0 +1,119 @@
+// Shared device/host helpers for the gfx950 (CDNA4) kernels of the mDT hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mdt_hip.h"
+
+namespace mdt {
+
+constexpr int WAVE = 64;
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// ---------------------------------------------------------------- error plumbing
+void set_error(const char* fmt, ...);
+#define MDT_CHECK_ARG(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::mdt::set_error(__VA_ARGS__);      \
+      return MDT_ERR_ARG;                 \
+    }                                     \
+  } while (0)
+#define MDT_UNSUPPORTED(...)              \
+  do {                                    \
+    ::mdt::set_error(__VA_ARGS__);        \
+    return MDT_ERR_UNSUPPORTED;           \
+  } while (0)
+int check_launch(const char* what);
+
+// ---------------------------------------------------------------- scalar conversions
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }  // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
+
+// ---------------------------------------------------------------- wave reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// reduce across the 4 lanes l, l+16, l+32, l+48 (rows of a 16x16 MFMA accumulator column group)
+__device__ __forceinline__ float quad16_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+// reduce across the 16 lanes that share lane>>4 (one accumulator row across its 16 columns)
+__device__ __forceinline__ float row16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------- math
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---------------------------------------------------------------- MFMA wrappers (16x16 tiles)
+// C/D layout (all dtypes): col = lane & 15, row = (lane >> 4) * 4 + reg.
+// f32:  A[row = lane&15][k = lane>>4],            B[k = lane>>4][col = lane&15]        (K = 4)
+// bf16: A[row = lane&15][k = 8*(lane>>4) + j],    B[k = 8*(lane>>4) + j][col = lane&15] (K = 32)
+__device__ __forceinline__ f32x4 mfma_f32(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// LDS address-space casts
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-col block of 16-bit elements is
+// delivered column-major — lane i of the group receives column i of the 4 rows
+// (cdna_hip_programming.md T10).  Lane 4q+p supplies the address of row q, cols 4p..4p+3.
+__device__ __forceinline__ bf16x4 lds_read_tr16(const bf16_t* lds_addr) {
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds_addr));
+  return __builtin_bit_cast(bf16x4, r);
+}
+
+// async global -> LDS, 16 bytes per lane; LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T> struct DType;
+template <> struct DType<float> { static constexpr int id = MDT_F32; };
+template <> struct DType<bf16_t> { static constexpr int id = MDT_BF16; };
+
+static inline size_t dtype_size(int dt) { return dt == MDT_BF16 ? 2 : 4; }
+
+}  // namespace mdt

@@ -1,0 +1,404 @@
+// GEMM kernels for the mDT hot path on gfx950.
+//
+//  * gemm_bf16_tile128: the workhorse.  bf16 operands, fp32 accumulate on
+//    v_mfma_f32_16x16x32_bf16; 128x128x64 tiles, 4 waves (2x2, 64x64 each), LDS
+//    double-buffered and filled by buffer_load ... lds (16 B / lane, no VGPR staging,
+//    out-of-range rows read as zero through the buffer descriptor).  Each operand may be
+//    k-contiguous (nn.Linear weights, activations in forward / dgrad) or k-major
+//    (both operands of the weight gradient dW = dY^T X): k-major tiles keep their
+//    memory layout in LDS and fragments are fetched with ds_read_b64_tr_b16.
+//    LDS images are XOR-swizzled on the *source* address (LDS-DMA writes lane-linear).
+//  * gemm_generic: any shape / stride / dtype mix on v_mfma_f32_16x16x4_f32 (exact
+//    fp32 FMA chains) — the fp32 parity path and the fallback for odd shapes.
+//
+// Replaces the nn.Linear calls of the reference (see include/mdt_hip.h, mdt_gemm).
+#include "common.hpp"
+
+namespace mdt {
+
+struct GemmParams {
+  int64_t M, N, K;
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  void* C; int64_t ldc;
+  int epilogue; float alpha;
+  const void* bias; const void* residual; int64_t ldr;
+  void* aux; int64_t ldaux;
+  int split_k; int64_t k_chunk;
+  int tiles_m, tiles_n;
+};
+
+// ------------------------------------------------------------------ shared epilogue
+template <typename TIn, typename TOut>
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t row, int64_t col, float v) {
+  if (row >= p.M || col >= p.N) return;
+  v *= p.alpha;
+  if (p.epilogue & MDT_EPI_BIAS) v += to_f32(((const TIn*)p.bias)[col]);
+  if (p.epilogue & MDT_EPI_GELU) {
+    if (p.aux) ((TIn*)p.aux)[row * p.ldaux + col] = from_f32<TIn>(v);
+    // the saved pre-activation is what backward differentiates at: use the rounded value
+    if (p.aux) v = to_f32(from_f32<TIn>(v));
+    v = gelu_erf(v);
+  }
+  if (p.epilogue & MDT_EPI_DGELU) v *= gelu_erf_grad(to_f32(((const TIn*)p.aux)[row * p.ldaux + col]));
+  if (p.epilogue & MDT_EPI_RESIDUAL) v += to_f32(((const TIn*)p.residual)[row * p.ldr + col]);
+  TOut* c = (TOut*)p.C + row * p.ldc + col;
+  if constexpr (sizeof(TOut) == 4) {
+    if (p.epilogue & MDT_EPI_ATOMIC) { atomicAdd((float*)c, v); return; }
+  }
+  if (p.epilogue & MDT_EPI_ACCUM) v += to_f32(*c);
+  *c = from_f32<TOut>(v);
+}
+
+// ------------------------------------------------------------------ generic kernel
+// 64x64x16 tiles, 4 waves (2x2 of 32x32), operands converted to fp32 in LDS.
+template <typename TIn, typename TOut, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_generic_kernel(GemmParams p) {
+  constexpr int BM = 64, BN = 64, BK = 16, LD = 68;
+  __shared__ float As[BK][LD];
+  __shared__ float Bs[BK][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * p.k_chunk;
+  const int64_t kend = (kbeg + p.k_chunk < p.K) ? kbeg + p.k_chunk : p.K;
+  const TIn* A = (const TIn*)p.A;
+  const TIn* B = (const TIn*)p.B;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      int r, k;
+      if constexpr (!TA) { r = e >> 4; k = e & 15; } else { k = e >> 6; r = e & 63; }
+      const int64_t gr = m0 + r, gk = k0 + k;
+      float v = 0.f;
+      if (gr < p.M && gk < kend) v = to_f32(TA ? A[gk * p.lda + gr] : A[gr * p.lda + gk]);
+      As[k][r] = v;
+      int c, kb;
+      if constexpr (!TB) { c = e >> 4; kb = e & 15; } else { kb = e >> 6; c = e & 63; }
+      const int64_t gc = n0 + c, gkb = k0 + kb;
+      float w = 0.f;
+      if (gc < p.N && gkb < kend) w = to_f32(TB ? B[gkb * p.ldb + gc] : B[gc * p.ldb + gkb]);
+      Bs[kb][c] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[kk + (lane >> 4)][wr * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[kk + (lane >> 4)][wc * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f32(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        epilogue_store<TIn, TOut>(p, m0 + wr * 32 + i * 16 + (lane >> 4) * 4 + r,
+                                  n0 + wc * 32 + j * 16 + (lane & 15), acc[i][j][r]);
+}
+
+// ------------------------------------------------------------------ bf16 128x128x64 kernel
+constexpr int T_BM = 128, T_BN = 128, T_BK = 64;
+constexpr int T_TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand per stage
+
+// XOR swizzles (see DESIGN.md "LDS images"):
+//  k-contiguous tile [128 rows][64 k] (128-B rows, eight 16-B chunks): chunk ^= (row>>1)&7
+//    → every ds_read_b128 lane group covers 16 distinct 16-B slots of the 256-B bank row.
+//  k-major tile [64 k][128 cols] (256-B rows, eight 32-B blocks): block ^= (k&3)|((k>>3)&1)<<2
+//    → the 8 rows a 32-lane half touches in one ds_read_b64_tr_b16 fall on distinct banks.
+__device__ __forceinline__ int swz_kc(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int swz_km(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+// Issue the LDS-DMA loads of one operand tile (16 KiB = 16 pieces of 1 KiB; wave w
+// issues pieces w, w+4, w+8, w+12).  `rs` covers the operand from its first tile row.
+template <bool KM>
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, int64_t ld_bytes, int64_t k0, int col0,
+                                           char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave + i * 4;
+    unsigned voff;
+    if constexpr (!KM) {
+      // piece = 8 rows x 128 B; lane -> row piece*8 + lane/8, LDS chunk' = lane%8
+      const int row = piece * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ swz_kc(row);
+      voff = (unsigned)(row * ld_bytes + (k0 + chunk * 8) * 2);
+    } else {
+      // piece = 4 k-rows x 256 B; lane -> k piece*4 + lane/16, LDS 16-B chunk' = lane%16
+      const int k = piece * 4 + (lane >> 4);
+      const int c16 = lane & 15;
+      const int blk = (c16 >> 1) ^ swz_km(k);
+      voff = (unsigned)((k0 + k) * ld_bytes + (col0 + blk * 16 + (c16 & 1) * 8) * 2);
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_tile + piece * 1024), 16, voff, 0, 0, 0);
+  }
+}
+
+// Fragment of a 16(row|col) x 32(k) block for k-step ks (0/1) of the staged tile.
+template <bool KM>
+__device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int rc_base, int ks, int lane) {
+  if constexpr (!KM) {
+    const int row = rc_base + (lane & 15);
+    const int chunk = (ks * 4 + (lane >> 4)) ^ swz_kc(row);
+    return *(const bf16x8*)(lds_tile + row * 128 + chunk * 16);
+  } else {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int blk = rc_base >> 4;
+    const int k_lo = ks * 32 + g * 8 + q;
+    const int k_hi = k_lo + 4;
+    const bf16x4 lo = lds_read_tr16((const bf16_t*)(lds_tile + k_lo * 256 + ((blk ^ swz_km(k_lo)) * 32) + pp * 8));
+    const bf16x4 hi = lds_read_tr16((const bf16_t*)(lds_tile + k_hi * 256 + ((blk ^ swz_km(k_hi)) * 32) + pp * 8));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+}
+
+template <typename TOut, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_bf16_tile128(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (A 16K + B 16K)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // XCD-aware tile order: the blocks sharing an XCD (blockIdx % 8) walk one contiguous
+  // chunk of the row-major tile grid, so an A row panel is reused from that XCD's L2.
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int64_t m0 = (int64_t)tm * T_BM, n0 = (int64_t)tn * T_BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * p.k_chunk;
+  const int64_t kend = (kbeg + p.k_chunk < p.K) ? kbeg + p.k_chunk : p.K;
+  const int nk = (int)((kend - kbeg + T_BK - 1) / T_BK);
+
+  const int64_t lda_b = p.lda * 2, ldb_b = p.ldb * 2;
+  // descriptors based at the first row this block touches (32-bit offsets stay small)
+  const char* a_base;
+  const char* b_base;
+  int64_t a_bytes, b_bytes;
+  if constexpr (!A_KM) { a_base = (const char*)p.A + m0 * lda_b; a_bytes = (p.M - m0) * lda_b; }
+  else { a_base = (const char*)p.A + kbeg * lda_b; a_bytes = (kend - kbeg) * lda_b; }
+  if constexpr (!B_KM) { b_base = (const char*)p.B + n0 * ldb_b; b_bytes = (p.N - n0) * ldb_b; }
+  else { b_base = (const char*)p.B + kbeg * ldb_b; b_bytes = (kend - kbeg) * ldb_b; }
+  const unsigned a_rec = (unsigned)(a_bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : a_bytes);
+  const unsigned b_rec = (unsigned)(b_bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : b_bytes);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, a_rec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, b_rec, 0x00020000);
+  // k offsets are relative to the descriptor base: k-contiguous operands start at
+  // absolute k (base = row m0, column 0), k-major ones at kbeg.
+  const int64_t a_k0 = A_KM ? 0 : kbeg, b_k0 = B_KM ? 0 : kbeg;
+  const int a_col0 = A_KM ? (int)m0 : 0, b_col0 = B_KM ? (int)n0 : 0;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    stage_tile<A_KM>(rsA, lda_b, a_k0, a_col0, smem, wave, lane);
+    stage_tile<B_KM>(rsB, ldb_b, b_k0, b_col0, smem + T_TILE_BYTES, wave, lane);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * 2 * T_TILE_BYTES;
+    char* nxt = smem + ((kt + 1) & 1) * 2 * T_TILE_BYTES;
+    // own loads of tile kt landed (vmcnt(0) inserted by the compiler for the LDS-DMA)
+    // + everyone finished reading the buffer tile kt+1 is about to overwrite
+    __syncthreads();
+    if (kt + 1 < nk) {
+      stage_tile<A_KM>(rsA, lda_b, a_k0 + (int64_t)(kt + 1) * T_BK, a_col0, nxt, wave, lane);
+      stage_tile<B_KM>(rsB, ldb_b, b_k0 + (int64_t)(kt + 1) * T_BK, b_col0, nxt + T_TILE_BYTES, wave, lane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = load_frag<A_KM>(cur, wr * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = load_frag<B_KM>(cur + T_TILE_BYTES, wc * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(a[i], b[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        epilogue_store<bf16_t, TOut>(p, m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r,
+                                     n0 + wc * 64 + j * 16 + (lane & 15), acc[i][j][r]);
+}
+
+// ------------------------------------------------------------------ helpers
+template <typename TIn, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void colsum_kernel(int64_t M, int64_t N, const TIn* X, int64_t ldx, float* out,
+                                                        int rows_per_block) {
+  // block = 256 threads: 64 columns x 4 row-lanes; grid.x = column groups, grid.y = row chunks
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
+  float s = 0.f;
+  if (c < N)
+    for (int64_t r = r0 + rl; r < r1; r += 4) s += to_f32(X[r * ldx + c]);
+  __shared__ float red[4][64];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < N) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(int64_t n, const TS* s, TD* d) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    d[i] = from_f32<TD>(to_f32(s[i]));
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void transpose_kernel(int64_t rows, int64_t cols, const TS* s, int64_t lds_, TD* d,
+                                                        int64_t ldd) {
+  __shared__ float tile[32][33];
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = to_f32(s[(r0 + i) * lds_ + c0 + tx]);
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < cols && r0 + tx < rows) d[(c0 + i) * ldd + r0 + tx] = from_f32<TD>(tile[tx][i]);
+}
+
+template <typename TIn, typename TOut>
+static int launch_generic(hipStream_t st, const GemmParams& p, int ta, int tb) {
+  dim3 grid((unsigned)((p.N + 63) / 64), (unsigned)((p.M + 63) / 64), (unsigned)p.split_k);
+  if (!ta && !tb) hipLaunchKernelGGL((gemm_generic_kernel<TIn, TOut, false, false>), grid, 256, 0, st, p);
+  else if (!ta && tb) hipLaunchKernelGGL((gemm_generic_kernel<TIn, TOut, false, true>), grid, 256, 0, st, p);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_generic_kernel<TIn, TOut, true, false>), grid, 256, 0, st, p);
+  else hipLaunchKernelGGL((gemm_generic_kernel<TIn, TOut, true, true>), grid, 256, 0, st, p);
+  return check_launch("gemm_generic");
+}
+
+template <typename TOut>
+static int launch_tile128(hipStream_t st, const GemmParams& p, int ta, int tb) {
+  dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)p.split_k);
+  const size_t lds = 4 * T_TILE_BYTES;
+  if (!ta && !tb) hipLaunchKernelGGL((gemm_bf16_tile128<TOut, false, false>), grid, 256, lds, st, p);
+  else if (!ta && tb) hipLaunchKernelGGL((gemm_bf16_tile128<TOut, false, true>), grid, 256, lds, st, p);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_bf16_tile128<TOut, true, false>), grid, 256, lds, st, p);
+  else hipLaunchKernelGGL((gemm_bf16_tile128<TOut, true, true>), grid, 256, lds, st, p);
+  return check_launch("gemm_bf16_tile128");
+}
+
+}  // namespace mdt
+
+using namespace mdt;
+
+extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int trans_b, int64_t M, int64_t N,
+                        int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                        int epilogue, float alpha, const void* bias, const void* residual, int64_t ldr, void* aux,
+                        int64_t ldaux, int split_k) {
+  MDT_CHECK_ARG(dtype == MDT_F32 || dtype == MDT_BF16, "mdt_gemm: bad dtype %d", dtype);
+  MDT_CHECK_ARG(out_dtype == MDT_F32 || out_dtype == MDT_BF16, "mdt_gemm: bad out_dtype %d", out_dtype);
+  MDT_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "mdt_gemm: negative shape");
+  if (M == 0 || N == 0) return MDT_OK;
+  MDT_CHECK_ARG(A && B && C, "mdt_gemm: null operand");
+  MDT_CHECK_ARG(!(epilogue & MDT_EPI_BIAS) || bias, "mdt_gemm: MDT_EPI_BIAS without bias");
+  MDT_CHECK_ARG(!(epilogue & MDT_EPI_RESIDUAL) || residual, "mdt_gemm: MDT_EPI_RESIDUAL without residual");
+  MDT_CHECK_ARG(!(epilogue & MDT_EPI_DGELU) || aux, "mdt_gemm: MDT_EPI_DGELU without aux");
+  MDT_CHECK_ARG(!(epilogue & MDT_EPI_ATOMIC) || out_dtype == MDT_F32, "mdt_gemm: MDT_EPI_ATOMIC needs fp32 C");
+  MDT_CHECK_ARG(dtype == MDT_BF16 || out_dtype == MDT_F32, "mdt_gemm: fp32 inputs need fp32 output");
+  if (split_k < 1) split_k = 1;
+  MDT_CHECK_ARG(split_k == 1 || (epilogue & MDT_EPI_ATOMIC), "mdt_gemm: split_k > 1 needs MDT_EPI_ATOMIC");
+  MDT_CHECK_ARG(split_k == 1 || !(epilogue & (MDT_EPI_BIAS | MDT_EPI_GELU | MDT_EPI_RESIDUAL | MDT_EPI_DGELU)),
+                "mdt_gemm: split_k > 1 supports only the plain accumulate epilogue");
+  hipStream_t st = (hipStream_t)stream;
+  GemmParams p;
+  p.M = M; p.N = N; p.K = K; p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+  p.epilogue = epilogue; p.alpha = alpha; p.bias = bias; p.residual = residual; p.ldr = ldr;
+  p.aux = aux; p.ldaux = ldaux; p.split_k = split_k;
+  // tile128 contract: bf16, output dims that are tiled along a contiguous axis must be
+  // whole tiles, 16-B aligned rows.
+  bool fast = dtype == MDT_BF16 && K > 0;
+  if (fast) {
+    const bool a_ok = trans_a ? (M % T_BM == 0) : (K % T_BK == 0);
+    const bool b_ok = trans_b ? (N % T_BN == 0) : (K % T_BK == 0);
+    const bool al = (lda % 8 == 0) && (ldb % 8 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
+    // 32-bit buffer offsets: one 128-row panel (k-contiguous) or one k-chunk (k-major) must stay < 4 GiB
+    fast = a_ok && b_ok && al && (N % T_BN == 0 || !trans_b) && lda * 2 * 128 < (1ll << 31) && ldb * 2 * 128 < (1ll << 31);
+    if (!trans_b && N % T_BN != 0) fast = false;  // B rows beyond N would alias the next tensor
+  }
+  if (fast) {
+    int64_t chunk = ((K + split_k - 1) / split_k + T_BK - 1) / T_BK * T_BK;
+    p.k_chunk = chunk;
+    p.split_k = (int)((K + chunk - 1) / chunk);
+    p.tiles_m = (int)((M + T_BM - 1) / T_BM);
+    p.tiles_n = (int)(N / T_BN);
+    if ((trans_a || trans_b) && chunk * (trans_a ? lda : ldb) * 2 >= (1ll << 32)) fast = false;
+  }
+  if (fast) {
+    return out_dtype == MDT_F32 ? launch_tile128<float>(st, p, trans_a, trans_b)
+                                : launch_tile128<bf16_t>(st, p, trans_a, trans_b);
+  }
+  int64_t chunk = ((K + split_k - 1) / split_k + 15) / 16 * 16;
+  if (chunk < 16) chunk = 16;
+  p.k_chunk = chunk;
+  p.split_k = K > 0 ? (int)((K + chunk - 1) / chunk) : 1;
+  if (dtype == MDT_F32) return launch_generic<float, float>(st, p, trans_a, trans_b);
+  return out_dtype == MDT_F32 ? launch_generic<bf16_t, float>(st, p, trans_a, trans_b)
+                              : launch_generic<bf16_t, bf16_t>(st, p, trans_a, trans_b);
+}
+
+extern "C" int mdt_colsum(void* stream, int dtype, int64_t M, int64_t N, const void* X, int64_t ldx, float* out) {
+  MDT_CHECK_ARG(X && out, "mdt_colsum: null pointer");
+  if (M == 0 || N == 0) return MDT_OK;
+  const int rows_per_block = 512;
+  dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rows_per_block - 1) / rows_per_block));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDT_F32) hipLaunchKernelGGL((colsum_kernel<float, 256>), grid, 256, 0, st, M, N, (const float*)X, ldx, out, rows_per_block);
+  else if (dtype == MDT_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t, 256>), grid, 256, 0, st, M, N, (const bf16_t*)X, ldx, out, rows_per_block);
+  else MDT_UNSUPPORTED("mdt_colsum: dtype %d", dtype);
+  return check_launch("colsum");
+}
+
+extern "C" int mdt_cast(void* stream, int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst) {
+  if (n == 0) return MDT_OK;
+  MDT_CHECK_ARG(src && dst, "mdt_cast: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  if (src_dtype == MDT_F32 && dst_dtype == MDT_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, 256, 0, st, n, (const float*)src, (bf16_t*)dst);
+  else if (src_dtype == MDT_BF16 && dst_dtype == MDT_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, 256, 0, st, n, (const bf16_t*)src, (float*)dst);
+  else if (src_dtype == MDT_F32 && dst_dtype == MDT_F32) hipLaunchKernelGGL((cast_kernel<float, float>), grid, 256, 0, st, n, (const float*)src, (float*)dst);
+  else if (src_dtype == MDT_BF16 && dst_dtype == MDT_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid, 256, 0, st, n, (const bf16_t*)src, (bf16_t*)dst);
+  else MDT_UNSUPPORTED("mdt_cast: dtypes %d -> %d", src_dtype, dst_dtype);
+  return check_launch("cast");
+}
+
+extern "C" int mdt_transpose2d(void* stream, int src_dtype, int dst_dtype, int64_t rows, int64_t cols, const void* src,
+                               int64_t lds_, void* dst, int64_t ldd) {
+  if (rows == 0 || cols == 0) return MDT_OK;
+  MDT_CHECK_ARG(src && dst, "mdt_transpose2d: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+  if (src_dtype == MDT_F32 && dst_dtype == MDT_BF16) hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, 256, 0, st, rows, cols, (const float*)src, lds_, (bf16_t*)dst, ldd);
+  else if (src_dtype == MDT_BF16 && dst_dtype == MDT_BF16) hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, 256, 0, st, rows, cols, (const bf16_t*)src, lds_, (bf16_t*)dst, ldd);
+  else if (src_dtype == MDT_F32 && dst_dtype == MDT_F32) hipLaunchKernelGGL((transpose_kernel<float, float>), grid, 256, 0, st, rows, cols, (const float*)src, lds_, (float*)dst, ldd);
+  else MDT_UNSUPPORTED("mdt_transpose2d: dtypes %d -> %d", src_dtype, dst_dtype);
+  return check_launch("transpose2d");
+}

@@ -1,0 +1,109 @@
+// Host-side pieces of the C ABI: error plumbing and the native packer (tree structure
+// tensors), compiled with hipcc as plain C++.
+#include <stdarg.h>
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <vector>
+
+#include "common.hpp"
+
+namespace mdt {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return MDT_ERR_LAUNCH;
+  }
+  return MDT_OK;
+}
+
+}  // namespace mdt
+
+extern "C" int mdt_abi_version(void) { return MDT_ABI_VERSION; }
+extern "C" const char* mdt_last_error_string(void) { return mdt::g_err; }
+
+// --------------------------------------------------------------------------- packer
+// (up, down) hops through the lowest common ancestor → 21-bucket spatial index
+// (ascending Cantor value of the sorted pair, anything with a component > 5 shares the
+// (5,5) bucket), tree distance, undirected degree — data/pyg_datasets/pre_processing.py:
+// 18-69 and experiments/hateful_discussions/datasets/hateful_discussions.py:242-264 —
+// then the collator's shifts, padding and distance clipping (data/collator.py:38-66,
+// 122-126, 156-164), written straight into the padded batch tensors.
+namespace {
+
+struct SpatialTable {
+  int t[6][6];
+  SpatialTable() {
+    std::vector<int> vals;
+    for (int a = 0; a < 6; ++a)
+      for (int b = a; b < 6; ++b) vals.push_back((a + b) * (a + b + 1) / 2 + a);
+    std::sort(vals.begin(), vals.end());
+    for (int a = 0; a < 6; ++a)
+      for (int b = 0; b < 6; ++b) {
+        const int lo = std::min(a, b), hi = std::max(a, b);
+        const int c = (lo + hi) * (lo + hi + 1) / 2 + lo;
+        t[a][b] = (int)(std::lower_bound(vals.begin(), vals.end(), c) - vals.begin());
+      }
+  }
+};
+const SpatialTable kTable;
+
+}  // namespace
+
+extern "C" int mdt_pack_structure(int B, const int64_t* n_nodes, const int64_t* const* parents, int nmax,
+                                  int spatial_pos_max, float* attn_bias, int32_t* spatial_pos, int64_t* in_degree) {
+  MDT_CHECK_ARG(B >= 0 && nmax >= 1 && n_nodes && parents && attn_bias && spatial_pos && in_degree,
+                "pack_structure: bad arguments");
+  const int T = nmax + 1;
+  const float ninf = -std::numeric_limits<float>::infinity();
+  std::vector<int> depth, anc_pos;
+  for (int b = 0; b < B; ++b) {
+    const int n = (int)n_nodes[b];
+    const int64_t* par = parents[b];
+    MDT_CHECK_ARG(n >= 1 && n <= nmax, "pack_structure: tree %d has %d nodes (nmax %d)", b, n, nmax);
+    float* ab = attn_bias + (int64_t)b * T * T;
+    int32_t* sp = spatial_pos + (int64_t)b * nmax * nmax;
+    int64_t* deg = in_degree + (int64_t)b * nmax;
+    depth.assign(n, 0);
+    for (int i = 0; i < n; ++i) {
+      MDT_CHECK_ARG(par[i] < i && par[i] >= -1 && (i == 0) == (par[i] < 0),
+                    "pack_structure: tree %d node %d: parents must precede children (root first)", b, i);
+      depth[i] = par[i] < 0 ? 0 : depth[par[i]] + 1;
+    }
+    // padding: columns beyond the tree are -inf on every row, rows beyond it are 0 over real columns
+    for (int i = 0; i < T; ++i)
+      for (int j = 0; j < T; ++j) ab[(int64_t)i * T + j] = (j <= n) ? 0.f : ninf;
+    std::fill(sp, sp + (int64_t)nmax * nmax, 0);
+    std::fill(deg, deg + nmax, (int64_t)0);
+    for (int i = 0; i < n; ++i) {
+      deg[i] += 1;  // the collator's +1 shift
+      if (par[i] >= 0) { deg[i] += 1; deg[par[i]] += 1; }
+    }
+    for (int i = 0; i < n; ++i) {
+      for (int j = 0; j < n; ++j) {
+        int a = i, c = j;  // walk both to their lowest common ancestor
+        int up = 0, down = 0;
+        while (a != c) {
+          if (depth[a] >= depth[c]) { a = (int)par[a]; ++up; }
+          else { c = (int)par[c]; ++down; }
+        }
+        const int bucket = (up <= 5 && down <= 5) ? kTable.t[up][down] : kTable.t[5][5];
+        sp[(int64_t)i * nmax + j] = bucket + 1;
+        if (up + down >= spatial_pos_max) ab[(int64_t)(i + 1) * T + (j + 1)] = ninf;
+      }
+    }
+  }
+  return MDT_OK;
+}

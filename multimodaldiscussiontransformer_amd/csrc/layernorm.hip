@@ -1,0 +1,243 @@
+// LayerNorm forward / backward: one wavefront per row, the row held in registers
+// (two-pass mean / variance, no re-read), 16-byte vector loads, fp32 statistics.
+// HBM-bound: algorithmic bytes = rows * D * sizeof(T) * 2 (fwd), * 3 (+ residual 4) (bwd).
+// Replaces fairseq LayerNorm / HF nn.LayerNorm (modules/graphormer_graph_encoder_layer.py:
+// 127-130,138-141; modules/multigraphormer_graph_encoder.py:400-403; HF BertLayer/ViTLayer).
+#include "common.hpp"
+
+namespace mdt {
+
+template <typename T> struct Vec;  // 16-byte vector of T
+template <> struct Vec<float> {
+  static constexpr int N = 4;
+  f32x4 v;
+  __device__ __forceinline__ float get(int i) const { return v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec<bf16_t> {
+  static constexpr int N = 8;
+  bf16x8 v;
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
+};
+
+// NV = number of 16-B vectors per lane: D = NV * 64 * Vec<T>::N exactly, or masked tail.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int D, const T* __restrict__ x, int64_t ldx,
+                                                            const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                            float eps, T* __restrict__ y, int64_t ldy,
+                                                            float* __restrict__ mean, float* __restrict__ rstd) {
+  constexpr int VN = Vec<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * ldx;
+  Vec<T> xv[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * VN;
+    if (c < D) {
+      xv[i] = *(const Vec<T>*)(xr + c);
+#pragma unroll
+      for (int j = 0; j < VN; ++j) s += xv[i].get(j);
+    }
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * VN;
+    if (c < D) {
+#pragma unroll
+      for (int j = 0; j < VN; ++j) { const float d = xv[i].get(j) - mu; q += d * d; }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+  T* yr = y + row * ldy;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * VN;
+    if (c < D) {
+      const Vec<T> g = *(const Vec<T>*)(gamma + c);
+      const Vec<T> b = *(const Vec<T>*)(beta + c);
+      Vec<T> o;
+#pragma unroll
+      for (int j = 0; j < VN; ++j) o.set(j, (xv[i].get(j) - mu) * rs * g.get(j) + b.get(j));
+      *(Vec<T>*)(yr + c) = o;
+    }
+  }
+}
+
+// Backward: each wave walks rows_per_wave consecutive rows, keeps per-lane partial
+// dgamma / dbeta in registers, the block combines them through LDS and issues one
+// float atomic per column.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D, const T* __restrict__ dy, int64_t lddy,
+                                                            const T* __restrict__ x, int64_t ldx,
+                                                            const T* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const T* __restrict__ add,
+                                                            int64_t ldadd, T* __restrict__ dx, int64_t lddx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int rows_per_wave) {
+  constexpr int VN = Vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = (float*)smem_raw;  // [2][4 waves][NV*64*VN]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
+  const int64_t r1 = (r0 + rows_per_wave < rows) ? r0 + rows_per_wave : rows;
+  float pg[NV][VN], pb[NV][VN];
+  Vec<T> gv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * VN;
+    if (c < D) gv[i] = *(const Vec<T>*)(gamma + c);
+#pragma unroll
+    for (int j = 0; j < VN; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; }
+  }
+  for (int64_t row = r0; row < r1; ++row) {
+    const float mu = mean[row], rs = rstd[row];
+    Vec<T> xv[NV], gy[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * VN;
+      if (c < D) {
+        xv[i] = *(const Vec<T>*)(x + row * ldx + c);
+        gy[i] = *(const Vec<T>*)(dy + row * lddy + c);
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+          const float xh = (xv[i].get(j) - mu) * rs;
+          const float g = gy[i].get(j);
+          const float gg = g * gv[i].get(j);
+          s1 += gg;
+          s2 += gg * xh;
+          pg[i][j] += g * xh;
+          pb[i][j] += g;
+        }
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * VN;
+      if (c < D) {
+        Vec<T> o, a;
+        if (add) a = *(const Vec<T>*)(add + row * ldadd + c);
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+          const float xh = (xv[i].get(j) - mu) * rs;
+          float v = rs * (gy[i].get(j) * gv[i].get(j) - m1 - xh * m2);
+          if (add) v += a.get(j);
+          o.set(j, v);
+        }
+        *(Vec<T>*)(dx + row * lddx + c) = o;
+      }
+    }
+  }
+  if (!dgamma && !dbeta) return;
+  const int W = NV * 64 * VN;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < VN; ++j) {
+      const int c = (i * 64 + lane) * VN + j;
+      red[wave * W + c] = pg[i][j];
+      red[(4 + wave) * W + c] = pb[i][j];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    const float g = red[c] + red[W + c] + red[2 * W + c] + red[3 * W + c];
+    const float b = red[4 * W + c] + red[5 * W + c] + red[6 * W + c] + red[7 * W + c];
+    if (dgamma) atomicAdd(dgamma + c, g);
+    if (dbeta) atomicAdd(dbeta + c, b);
+  }
+}
+
+template <typename T>
+static int ln_fwd_dispatch(hipStream_t st, int64_t rows, int D, const void* x, int64_t ldx, const void* gamma,
+                           const void* beta, float eps, void* y, int64_t ldy, float* mean, float* rstd) {
+  constexpr int VN = Vec<T>::N;
+  const int nv = (D + 64 * VN - 1) / (64 * VN);
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+#define LN_FWD(NV_)                                                                                          \
+  hipLaunchKernelGGL((layernorm_fwd_kernel<T, NV_>), grid, 256, 0, st, rows, D, (const T*)x, ldx,          \
+                     (const T*)gamma, (const T*)beta, eps, (T*)y, ldy, mean, rstd)
+  switch (nv) {
+    case 1: LN_FWD(1); break;
+    case 2: LN_FWD(2); break;
+    case 3: LN_FWD(3); break;
+    case 4: LN_FWD(4); break;
+    case 6: LN_FWD(6); break;
+    case 8: LN_FWD(8); break;
+    default: MDT_UNSUPPORTED("layernorm: D=%d not supported (vectors per lane %d)", D, nv);
+  }
+#undef LN_FWD
+  return check_launch("layernorm_fwd");
+}
+
+template <typename T>
+static int ln_bwd_dispatch(hipStream_t st, int64_t rows, int D, const void* dy, int64_t lddy, const void* x, int64_t ldx,
+                           const void* gamma, const float* mean, const float* rstd, const void* add, int64_t ldadd,
+                           void* dx, int64_t lddx, float* dgamma, float* dbeta) {
+  constexpr int VN = Vec<T>::N;
+  const int nv = (D + 64 * VN - 1) / (64 * VN);
+  // ~2048 workgroups x 4 waves, at least 4 rows per wave so the column atomics stay few
+  int rpw = (int)((rows + 2048 * 4 - 1) / (2048 * 4));
+  if (rpw < 4) rpw = 4;
+  const unsigned grid = (unsigned)((rows + 4 * rpw - 1) / (4 * rpw));
+#define LN_BWD(NV_)                                                                                              \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV_>), grid, 256, (size_t)(8 * NV_ * 64 * VN * 4), st, rows, D,    \
+                     (const T*)dy, lddy, (const T*)x, ldx, (const T*)gamma, mean, rstd, (const T*)add, ldadd,    \
+                     (T*)dx, lddx, dgamma, dbeta, rpw)
+  switch (nv) {
+    case 1: LN_BWD(1); break;
+    case 2: LN_BWD(2); break;
+    case 3: LN_BWD(3); break;
+    case 4: LN_BWD(4); break;
+    case 6: LN_BWD(6); break;
+    case 8: LN_BWD(8); break;
+    default: MDT_UNSUPPORTED("layernorm: D=%d not supported (vectors per lane %d)", D, nv);
+  }
+#undef LN_BWD
+  return check_launch("layernorm_bwd");
+}
+
+}  // namespace mdt
+
+using namespace mdt;
+
+static int ln_check(int dtype, int D, int64_t ld0, int64_t ld1, const void* p0, const void* p1) {
+  const int vn = dtype == MDT_BF16 ? 8 : 4;
+  MDT_CHECK_ARG(dtype == MDT_F32 || dtype == MDT_BF16, "layernorm: bad dtype %d", dtype);
+  MDT_CHECK_ARG(D > 0 && D % vn == 0, "layernorm: D=%d must be a multiple of %d", D, vn);
+  MDT_CHECK_ARG(ld0 % vn == 0 && ld1 % vn == 0, "layernorm: row strides must be multiples of %d elements", vn);
+  MDT_CHECK_ARG((((uintptr_t)p0 | (uintptr_t)p1) & 15) == 0, "layernorm: pointers must be 16-byte aligned");
+  return MDT_OK;
+}
+
+extern "C" int mdt_layernorm_fwd(void* stream, int dtype, int64_t rows, int D, const void* x, int64_t ldx,
+                                 const void* gamma, const void* beta, float eps, void* y, int64_t ldy, float* mean,
+                                 float* rstd) {
+  if (rows == 0) return MDT_OK;
+  MDT_CHECK_ARG(x && y && gamma && beta, "layernorm_fwd: null pointer");
+  if (int e = ln_check(dtype, D, ldx, ldy, x, y)) return e;
+  MDT_CHECK_ARG((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "layernorm_fwd: gamma/beta must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == MDT_F32 ? ln_fwd_dispatch<float>(st, rows, D, x, ldx, gamma, beta, eps, y, ldy, mean, rstd)
+                          : ln_fwd_dispatch<bf16_t>(st, rows, D, x, ldx, gamma, beta, eps, y, ldy, mean, rstd);
+}
+
+extern "C" int mdt_layernorm_bwd(void* stream, int dtype, int64_t rows, int D, const void* dy, int64_t lddy,
+                                 const void* x, int64_t ldx, const void* gamma, const float* mean, const float* rstd,
+                                 const void* add, int64_t ldadd, void* dx, int64_t lddx, float* dgamma, float* dbeta) {
+  if (rows == 0) return MDT_OK;
+  MDT_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
+  if (int e = ln_check(dtype, D, lddy, ldx, dy, x)) return e;
+  if (int e = ln_check(dtype, D, lddx, add ? ldadd : lddx, dx, add ? add : dx)) return e;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == MDT_F32
+             ? ln_bwd_dispatch<float>(st, rows, D, dy, lddy, x, ldx, gamma, mean, rstd, add, ldadd, dx, lddx, dgamma, dbeta)
+             : ln_bwd_dispatch<bf16_t>(st, rows, D, dy, lddy, x, ldx, gamma, mean, rstd, add, ldadd, dx, lddx, dgamma, dbeta);
+}

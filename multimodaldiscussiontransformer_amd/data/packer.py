@@ -1,0 +1,148 @@
+"""Ragged-batch packer: discussion trees → the tensors the HIP path consumes.
+
+Replaces ``preprocess_item`` + ``collator`` of the reference
+(mDT/src/data/pyg_datasets/pre_processing.py:18-69, mDT/src/data/collator.py:69-179,
+``y_mask`` from mDT/src/data/dataset.py:210-213).  The structural integer tensors come
+from the native C++ packer (``mdt_pack_structure``) and are bit-exact with the
+reference; on top of the reference's padded dict this packer emits the CSR index vectors
+(comment ↔ graph row, image ↔ comment, labelled rows) that let every bottleneck-token
+exchange on the device run without ``nonzero`` / host synchronisation.  Host buffers are
+pinned when a GPU is present so the H2D copies are asynchronous.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+
+def pack_structure(parents: List[np.ndarray], spatial_pos_max: int, nmax: Optional[int] = None):
+    """→ (attn_bias f32[B,T,T], spatial_pos i32[B,N,N], in_degree i64[B,N]) as numpy arrays."""
+    B = len(parents)
+    parents = [np.ascontiguousarray(p, dtype=np.int64) for p in parents]
+    n_nodes = np.asarray([len(p) for p in parents], dtype=np.int64)
+    nmax = int(n_nodes.max()) if nmax is None else nmax
+    T = nmax + 1
+    attn_bias = np.empty((B, T, T), dtype=np.float32)
+    spatial_pos = np.empty((B, nmax, nmax), dtype=np.int32)
+    in_degree = np.empty((B, nmax), dtype=np.int64)
+    ptrs = (C.c_void_p * B)(*[p.ctypes.data for p in parents])
+    L.check(L.lib.mdt_pack_structure(B, n_nodes.ctypes.data, C.cast(ptrs, C.c_void_p), nmax, int(spatial_pos_max),
+                                     attn_bias.ctypes.data, spatial_pos.ctypes.data, in_degree.ctypes.data),
+            "mdt_pack_structure")
+    return attn_bias, spatial_pos, in_degree
+
+
+@dataclass
+class PackedBatch:
+    """Device-resident batch.  ``batched_data`` is the reference's dict (same keys, dtypes and
+    padding); the remaining fields are the ragged index vectors of the fused path."""
+    B: int
+    N: int                      # padded nodes per tree
+    M: int                      # real comments in the batch
+    I: int                      # image-bearing comments
+    L: int                      # text tokens per comment
+    batched_data: dict
+    ids: torch.Tensor           # i32[M, L]
+    types: torch.Tensor         # i32[M, L]
+    text_mask: torch.Tensor     # u8[M, L]   1 = real token
+    node_row: torch.Tensor      # i32[B*N]   comment index of (b, n) or -1
+    graph_row: torch.Tensor     # i32[M]     b*T + 1 + n of comment m
+    degree: torch.Tensor        # i32[B*N]   shifted degree (0 = padding)
+    key_pad: torch.Tensor       # u8[B, T]   1 = padded graph key
+    attn_bias: torch.Tensor     # f32[B, T, T]
+    spatial_pos: torch.Tensor   # i32[B, N, N]
+    img_comment: torch.Tensor   # i32[I]     comment index of image i
+    images: Optional[torch.Tensor]   # f32[I, 3, H, W]
+    label_rows: torch.Tensor    # i32[#lab]  comment index of each label
+    targets: torch.Tensor       # i32[#lab]
+    n_labels: int = 0
+    extras: dict = field(default_factory=dict)
+
+    @property
+    def T(self):
+        return self.N + 1
+
+
+def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_blocking=True) -> PackedBatch:
+    B = len(trees)
+    n_nodes = [len(t["parent"]) for t in trees]
+    N = max(n_nodes)
+    Lq = trees[0]["input_ids"].shape[1]
+    M = int(sum(n_nodes))
+    attn_bias, spatial_pos, in_degree = pack_structure([t["parent"] for t in trees], spatial_pos_max, N)
+    pin = torch.cuda.is_available() and str(device).startswith("cuda")
+
+    def host(shape, dtype):
+        return torch.zeros(shape, dtype=dtype, pin_memory=pin)
+
+    x = host((B, N, Lq), torch.int64)
+    tt = host((B, N, Lq), torch.int64)
+    am = host((B, N, Lq), torch.int64)
+    ids = host((M, Lq), torch.int32)
+    types = host((M, Lq), torch.int32)
+    tmask = host((M, Lq), torch.uint8)
+    node_row = torch.full((B * N,), -1, dtype=torch.int32, pin_memory=pin)
+    graph_row = host((M,), torch.int32)
+    key_pad = host((B, N + 1), torch.uint8)
+    img_index, images, ys, y_masks = [], [], [], []
+    m = 0
+    for b, t in enumerate(trees):
+        n = n_nodes[b]
+        ii, ty, at = (torch.from_numpy(np.ascontiguousarray(t[k])) for k in ("input_ids", "token_type_ids", "attention_mask"))
+        x[b, :n], tt[b, :n], am[b, :n] = ii, ty, at
+        ids[m:m + n], types[m:m + n], tmask[m:m + n] = ii.int(), ty.int(), at.to(torch.uint8)
+        node_row[b * N:b * N + n] = torch.arange(m, m + n, dtype=torch.int32)
+        graph_row[m:m + n] = torch.arange(b * (N + 1) + 1, b * (N + 1) + 1 + n, dtype=torch.int32)
+        key_pad[b, n + 1:] = 1
+        img_index.append(np.asarray(t["image_index"], dtype=bool))
+        if t["images"] is not None and len(t["images"]):
+            images.append(torch.from_numpy(np.ascontiguousarray(t["images"], dtype=np.float32)))
+        ys.append(np.asarray(t["y"], dtype=np.float32))
+        y_masks.append(np.asarray(t["y_mask"], dtype=bool))
+        m += n
+    token_mask = ~(x == 0).all(dim=2)                      # collator.py:141
+    if not bool(torch.equal(token_mask.sum(1), torch.tensor(n_nodes))):
+        raise ValueError("a comment with an all-zero input_ids row cannot be told from padding (collator.py:141)")
+    img_index = np.concatenate(img_index)
+    y = np.concatenate(ys)
+    y_mask = np.concatenate(y_masks)
+    img_comment = torch.from_numpy(np.nonzero(img_index)[0].astype(np.int32))
+    label_rows = torch.from_numpy(np.nonzero(y_mask)[0].astype(np.int32))
+    images_t = torch.cat(images) if images else None
+    if images_t is not None and pin:
+        images_t = images_t.pin_memory()
+    if images_t is not None and images_t.shape[0] != img_comment.numel():
+        raise ValueError("number of image tensors differs from the number of image-bearing comments")
+
+    def to(t):
+        return None if t is None else t.to(device, non_blocking=non_blocking)
+
+    in_deg_t = torch.from_numpy(in_degree)
+    bd = dict(
+        idx=torch.arange(B, dtype=torch.int64),
+        attn_bias=to(torch.from_numpy(attn_bias)),
+        spatial_pos=to(torch.from_numpy(spatial_pos)),
+        in_degree=to(in_deg_t),
+        x_token_mask=to(token_mask),
+        x=to(x), x_token_type_ids=to(tt), x_attention_mask=to(am),
+        x_images=to(images_t),
+        x_image_indexes=to(torch.from_numpy(img_index)),
+        y=to(torch.from_numpy(y)),
+        y_mask=to(torch.from_numpy(y_mask)),
+    )
+    bd["out_degree"] = bd["in_degree"]            # collator.py:171 — the same tensor object
+    pb = PackedBatch(
+        B=B, N=N, M=M, I=int(img_comment.numel()), L=Lq, batched_data=bd,
+        ids=to(ids), types=to(types), text_mask=to(tmask), node_row=to(node_row), graph_row=to(graph_row),
+        degree=to(in_deg_t.reshape(-1).int()), key_pad=to(key_pad), attn_bias=bd["attn_bias"],
+        spatial_pos=bd["spatial_pos"], img_comment=to(img_comment), images=bd["x_images"],
+        label_rows=to(label_rows), targets=to(torch.from_numpy(y.astype(np.int32))), n_labels=int(label_rows.numel()),
+    )
+    bd["_packed"] = pb                             # lets model(**net_input) find the CSR view
+    return pb

@@ -1,0 +1,243 @@
+"""Tensor-level wrappers over the C ABI (one per entry point of include/mdt_hip.h).
+
+These allocate outputs with torch, pass raw pointers + the current HIP stream, and never
+touch tensor contents on the host.  Autograd lives one level up (autograd.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import EPI_ACCUM, EPI_ATOMIC, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_RESIDUAL, check, dt, lib, ptr, stream
+
+__all__ = [
+    "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "graph_attn_bias",
+    "row_axpby", "row_scatter_add", "bert_embed_sum", "vit_patchify", "vit_assemble", "graph_node_feature",
+    "tanh_fwd", "tanh_bwd", "node_ce", "cast", "transpose2d",
+    "EPI_BIAS", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_ACCUM", "EPI_ATOMIC",
+]
+
+
+def _2d(t: torch.Tensor):
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D tensor (unit inner stride)"
+    return t.stride(0)
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out: Optional[torch.Tensor] = None,
+         out_dtype=None, bias=None, residual=None, aux=None, epilogue=0, alpha=1.0, split_k=1) -> torch.Tensor:
+    """out[M,N] = epilogue(alpha * op(a) @ op(b)); b is [N,K] unless trans_b (then [K,N])."""
+    lda, ldb = _2d(a), _2d(b)
+    M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    N = b.shape[1] if trans_b else b.shape[0]
+    kb = b.shape[0] if trans_b else b.shape[1]
+    assert kb == K, f"gemm: inner dimensions differ ({K} vs {kb})"
+    assert a.dtype == b.dtype
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype or a.dtype, device=a.device)
+    assert out.shape == (M, N)
+    if bias is not None:
+        epilogue |= EPI_BIAS
+        assert bias.dtype == a.dtype and bias.numel() == N and bias.is_contiguous()
+    if residual is not None:
+        epilogue |= EPI_RESIDUAL
+        assert residual.dtype == a.dtype and residual.shape == (M, N)
+    if aux is not None:
+        assert aux.dtype == a.dtype and aux.shape == (M, N)
+    check(lib.mdt_gemm(stream(), dt(a), dt(out), int(trans_a), int(trans_b), M, N, K, ptr(a), lda, ptr(b), ldb,
+                       ptr(out), _2d(out), epilogue, float(alpha), ptr(bias), ptr(residual),
+                       _2d(residual) if residual is not None else 0, ptr(aux), _2d(aux) if aux is not None else 0,
+                       int(split_k)), "mdt_gemm")
+    return out
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[n] += sum_m x[m, n] (fp32, atomics)."""
+    if out is None:
+        out = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    check(lib.mdt_colsum(stream(), dt(x), x.shape[0], x.shape[1], ptr(x), _2d(x), ptr(out)), "mdt_colsum")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps, out=None):
+    rows, D = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib.mdt_layernorm_fwd(stream(), dt(x), rows, D, ptr(x), _2d(x), ptr(gamma), ptr(beta), float(eps), ptr(out),
+                                _2d(out), ptr(mean), ptr(rstd)), "mdt_layernorm_fwd")
+    return out, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, add=None, dgamma=None, dbeta=None, dx=None):
+    rows, D = x.shape
+    if dx is None:
+        dx = torch.empty_like(x)
+    check(lib.mdt_layernorm_bwd(stream(), dt(x), rows, D, ptr(dy), _2d(dy), ptr(x), _2d(x), ptr(gamma), ptr(mean),
+                                ptr(rstd), ptr(add), _2d(add) if add is not None else 0, ptr(dx), _2d(dx),
+                                ptr(dgamma), ptr(dbeta)), "mdt_layernorm_bwd")
+    return dx
+
+
+def _attn_args(qkv, out, lse, nseq, S, H, hd, seq_stride, pos_stride, scale, key_mask, dense_bias, attn_bias,
+               spatial_pos, sp_table, virt, key_pad):
+    a = L.AttnFwdArgs()
+    a.dtype = dt(qkv)
+    a.nseq, a.S, a.H, a.hd = nseq, S, H, hd
+    a.seq_stride, a.pos_stride, a.scale = seq_stride, pos_stride, float(scale)
+    a.qkv, a.ld_qkv = ptr(qkv), _2d(qkv)
+    a.out, a.ld_out = ptr(out), _2d(out)
+    a.lse = ptr(lse)
+    a.key_mask = ptr(key_mask)
+    a.dense_bias = ptr(dense_bias)
+    a.attn_bias = ptr(attn_bias)
+    a.spatial_pos = ptr(spatial_pos)
+    a.sp_table = ptr(sp_table)
+    a.virt = ptr(virt)
+    a.key_pad = ptr(key_pad)
+    a.num_spatial = sp_table.shape[0] if sp_table is not None else 0
+    for t, want in ((key_mask, torch.uint8), (key_pad, torch.uint8), (dense_bias, torch.float32),
+                    (attn_bias, torch.float32), (spatial_pos, torch.int32)):
+        assert t is None or (t.dtype == want and t.is_contiguous()), f"attention: expected contiguous {want}"
+    return a
+
+
+def attention_fwd(qkv, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None, key_mask=None, dense_bias=None,
+                  attn_bias=None, spatial_pos=None, sp_table=None, virt=None, key_pad=None):
+    """qkv [rows, 3*D] → (out [rows, D], lse f32[nseq, H, S])."""
+    D = qkv.shape[1] // 3
+    hd = D // H
+    out = torch.zeros(qkv.shape[0], D, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(nseq, H, S, dtype=torch.float32, device=qkv.device)
+    a = _attn_args(qkv, out, lse, nseq, S, H, hd, S if seq_stride is None else seq_stride, pos_stride,
+                   hd ** -0.5 if scale is None else scale, key_mask, dense_bias, attn_bias, spatial_pos, sp_table,
+                   virt, key_pad)
+    check(lib.mdt_attention_fwd(stream(), C.byref(a)), "mdt_attention_fwd")
+    return out, lse
+
+
+def attention_bwd(dout, qkv, out, lse, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None, key_mask=None,
+                  dense_bias=None, attn_bias=None, spatial_pos=None, sp_table=None, virt=None, key_pad=None,
+                  want_dense_dbias=False, d_sp_table=None, d_virt=None):
+    D = qkv.shape[1] // 3
+    hd = D // H
+    dqkv = torch.zeros_like(qkv)
+    b = L.AttnBwdArgs()
+    b.f = _attn_args(qkv, out, lse, nseq, S, H, hd, S if seq_stride is None else seq_stride, pos_stride,
+                     hd ** -0.5 if scale is None else scale, key_mask, dense_bias, attn_bias, spatial_pos, sp_table,
+                     virt, key_pad)
+    b.dout, b.ld_dout = ptr(dout), _2d(dout)
+    b.dqkv, b.ld_dqkv = ptr(dqkv), _2d(dqkv)
+    dbias = None
+    if want_dense_dbias:
+        dbias = torch.zeros(nseq, H, S, S, dtype=torch.float32, device=qkv.device)
+    b.d_dense_bias = ptr(dbias)
+    b.d_sp_table = ptr(d_sp_table)
+    b.d_virt = ptr(d_virt)
+    check(lib.mdt_attention_bwd(stream(), C.byref(b)), "mdt_attention_bwd")
+    return dqkv, dbias
+
+
+def graph_attn_bias(attn_bias, spatial_pos, sp_table, virt):
+    nseq, S, _ = attn_bias.shape
+    H = sp_table.shape[1]
+    out = torch.empty(nseq, H, S, S, dtype=torch.float32, device=attn_bias.device)
+    check(lib.mdt_graph_attn_bias(stream(), dt(sp_table), nseq, S, H, ptr(attn_bias), ptr(spatial_pos), ptr(sp_table),
+                                  ptr(virt), ptr(out)), "mdt_graph_attn_bias")
+    return out
+
+
+def row_axpby(dst, nrows, *, di=None, d_stride=1, d_off=0, a=None, ai=None, a_stride=1, a_off=0, alpha=1.0,
+              b=None, bi=None, b_stride=1, b_off=0, beta=1.0, accumulate=False):
+    """dst[di(r)] = alpha*a[ai(r)] + beta*b[bi(r)] (+ dst); 2-D row-major tensors, int32 index vectors."""
+    D = dst.shape[1]
+    for t in (di, ai, bi):
+        assert t is None or (t.dtype == torch.int32 and t.is_contiguous())
+    check(lib.mdt_row_axpby(stream(), dt(dst), nrows, D, ptr(dst), _2d(dst), ptr(di), d_stride, d_off,
+                            ptr(a), _2d(a) if a is not None else 0, ptr(ai), a_stride, a_off, float(alpha),
+                            ptr(b), _2d(b) if b is not None else 0, ptr(bi), b_stride, b_off, float(beta),
+                            int(accumulate)), "mdt_row_axpby")
+    return dst
+
+
+def row_scatter_add(table_f32, idx, src, nrows, *, s_stride=1, s_off=0):
+    assert table_f32.dtype == torch.float32 and idx.dtype == torch.int32
+    check(lib.mdt_row_scatter_add_f32(stream(), dt(src), nrows, table_f32.shape[1], ptr(table_f32), _2d(table_f32),
+                                      ptr(idx), ptr(src), _2d(src), s_stride, s_off), "mdt_row_scatter_add_f32")
+    return table_f32
+
+
+def bert_embed_sum(ids, types, word, pos, type_emb, out, *, out_seq_stride, out_off):
+    M, Lq = ids.shape
+    assert ids.dtype == torch.int32 and types.dtype == torch.int32 and ids.is_contiguous() and types.is_contiguous()
+    check(lib.mdt_bert_embed_sum(stream(), dt(word), M, Lq, ptr(ids), ptr(types), ptr(word), ptr(pos), ptr(type_emb),
+                                 word.shape[1], ptr(out), _2d(out), out_seq_stride, out_off), "mdt_bert_embed_sum")
+    return out
+
+
+def vit_patchify(images, patch, dtype):
+    I, Cc, HW, _ = images.shape
+    assert images.dtype == torch.float32 and images.is_contiguous()
+    g = HW // patch
+    cols = torch.empty(I * g * g, Cc * patch * patch, dtype=dtype, device=images.device)
+    check(lib.mdt_vit_patchify(stream(), dt(cols), I, Cc, HW, patch, ptr(images), ptr(cols), _2d(cols)),
+          "mdt_vit_patchify")
+    return cols
+
+
+def vit_assemble(patches, cls, pos, tokens, I, npatch, *, seq_stride, off):
+    check(lib.mdt_vit_assemble(stream(), dt(patches), I, npatch, patches.shape[1], ptr(patches), _2d(patches), ptr(cls),
+                               ptr(pos), ptr(tokens), _2d(tokens), seq_stride, off), "mdt_vit_assemble")
+    return tokens
+
+
+def graph_node_feature(src, node_row, degree, in_emb, out_emb, graph_token, B, T):
+    D = in_emb.shape[1]
+    x = torch.empty(B * T, D, dtype=in_emb.dtype, device=in_emb.device)
+    assert node_row.dtype == torch.int32 and degree.dtype == torch.int32
+    check(lib.mdt_graph_node_feature(stream(), dt(x), B, T, D, ptr(src), _2d(src) if src is not None else 0,
+                                     ptr(node_row), ptr(degree), ptr(in_emb), ptr(out_emb), ptr(graph_token), ptr(x),
+                                     _2d(x)), "mdt_graph_node_feature")
+    return x
+
+
+def tanh_fwd(x):
+    y = torch.empty_like(x)
+    check(lib.mdt_tanh_fwd(stream(), dt(x), x.numel(), ptr(x), ptr(y)), "mdt_tanh_fwd")
+    return y
+
+
+def tanh_bwd(y, dy):
+    dx = torch.empty_like(y)
+    check(lib.mdt_tanh_bwd(stream(), dt(y), y.numel(), ptr(y), ptr(dy), ptr(dx)), "mdt_tanh_bwd")
+    return dx
+
+
+def node_ce(logits, rows, targets, w_neg, w_pos, *, fp16_loss=True, grad_scale=1.0, want_grad=True):
+    """→ (loss f32[1], counters i32[4], dlogits or None)."""
+    M = logits.shape[0]
+    assert logits.shape[1] == 2 and logits.is_contiguous()
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    counters = torch.empty(4, dtype=torch.int32, device=logits.device)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    check(lib.mdt_node_ce(stream(), dt(logits), M, rows.numel(), ptr(logits), ptr(rows), ptr(targets), float(w_neg),
+                          float(w_pos), int(fp16_loss), float(grad_scale), ptr(loss), ptr(counters), ptr(dlogits)),
+          "mdt_node_ce")
+    return loss, counters, dlogits
+
+
+def cast(src, dtype):
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    assert src.is_contiguous()
+    check(lib.mdt_cast(stream(), dt(src), dt(dst), src.numel(), ptr(src), ptr(dst)), "mdt_cast")
+    return dst
+
+
+def transpose2d(src, dtype=None):
+    dst = torch.empty(src.shape[1], src.shape[0], dtype=dtype or src.dtype, device=src.device)
+    check(lib.mdt_transpose2d(stream(), dt(src), dt(dst), src.shape[0], src.shape[1], ptr(src), _2d(src), ptr(dst),
+                              _2d(dst)), "mdt_transpose2d")
+    return dst

@@ -1,0 +1,370 @@
+"""Kernel-level parity: every C-ABI entry point against a plain PyTorch fp32 computation
+of the same op on the CPU.  fp32 kernels: atol 2e-4 (1e-3 is the gate in north_star);
+bf16 kernels: compared on bf16-rounded inputs with a bf16-sized tolerance stated per test.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from multimodaldiscussiontransformer_amd import ops as o
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def dev(t, dtype=None):
+    t = t.cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(70, 35, 19), (128, 64, 64), (1, 2, 768), (200, 130, 100)])
+def test_gemm_generic_f32(ops, ta, tb, M, N, K):
+    a = rnd(K, M, seed=1) if ta else rnd(M, K, seed=1)
+    b = rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)
+    ref = (a.t() if ta else a) @ (b if tb else b.t())
+    out = ops.gemm(dev(a), dev(b), trans_a=bool(ta), trans_b=bool(tb))
+    torch.testing.assert_close(out.cpu(), ref, atol=2e-4, rtol=1e-5)
+
+
+def test_gemm_f32_epilogues(ops):
+    M, N, K = 50, 40, 36
+    a, b, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    u = a @ b.t() + bias
+    aux = torch.empty(M, N).cuda()
+    out = ops.gemm(dev(a), dev(b), bias=dev(bias), aux=aux, epilogue=ops.EPI_GELU)
+    torch.testing.assert_close(aux.cpu(), u, atol=2e-4, rtol=1e-5)
+    torch.testing.assert_close(out.cpu(), F.gelu(u), atol=2e-4, rtol=1e-5)
+    out = ops.gemm(dev(a), dev(b), bias=dev(bias), residual=dev(res))
+    torch.testing.assert_close(out.cpu(), u + res, atol=2e-4, rtol=1e-5)
+    # dgelu: out = (a @ b^T) * gelu'(aux)
+    x = u.clone().requires_grad_(True)
+    F.gelu(x).backward(a @ b.t())
+    out = ops.gemm(dev(a), dev(b), aux=dev(u), epilogue=ops.EPI_DGELU)
+    torch.testing.assert_close(out.cpu(), x.grad, atol=2e-4, rtol=1e-5)
+    # accumulate + atomic split-K
+    c = dev(res.clone())
+    ops.gemm(dev(a), dev(b), out=c, epilogue=ops.EPI_ACCUM)
+    torch.testing.assert_close(c.cpu(), res + a @ b.t(), atol=2e-4, rtol=1e-5)
+    c = dev(res.clone())
+    ops.gemm(dev(a), dev(b), out=c, epilogue=ops.EPI_ATOMIC, split_k=3)
+    torch.testing.assert_close(c.cpu(), res + a @ b.t(), atol=2e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 256, 192), (128, 384, 1024)])
+def test_gemm_bf16_tile128(ops, ta, tb, M, N, K):
+    if ta and M % 128:
+        M = 384
+    a = (rnd(K, M, seed=1) if ta else rnd(M, K, seed=1)).bfloat16()
+    b = (rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)).bfloat16()
+    af, bf = a.float(), b.float()
+    ref = (af.t() if ta else af) @ (bf if tb else bf.t())
+    out32 = ops.gemm(dev(a), dev(b), trans_a=bool(ta), trans_b=bool(tb), out_dtype=torch.float32)
+    # fp32 accumulation of exact bf16 products: only summation-order error
+    torch.testing.assert_close(out32.cpu(), ref, atol=1e-3, rtol=1e-4)
+    out16 = ops.gemm(dev(a), dev(b), trans_a=bool(ta), trans_b=bool(tb))
+    torch.testing.assert_close(out16.float().cpu(), ref, atol=0.06, rtol=1e-2)   # bf16 rounding of |x| <~ 8
+
+
+def test_gemm_bf16_wgrad_splitk_and_epilogues(ops):
+    # weight gradient shape: dW[N,K] = dY[M,N]^T X[M,K], reduction over M tokens with a ragged tail
+    M, N, K = 1000, 256, 128
+    dy, x = rnd(M, N, seed=5).bfloat16(), rnd(M, K, seed=6).bfloat16()
+    ref = dy.float().t() @ x.float()
+    c = torch.zeros(N, K, dtype=torch.float32).cuda()
+    ops.gemm(dev(dy), dev(x), trans_a=True, trans_b=True, out=c, epilogue=ops.EPI_ATOMIC, split_k=4)
+    torch.testing.assert_close(c.cpu(), ref, atol=5e-3, rtol=1e-4)
+    # bias + gelu + aux, bias + residual on the tile kernel
+    M, N, K = 260, 128, 128
+    a, b = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, scale=0.2).bfloat16()
+    bias, res = rnd(N, seed=3).bfloat16(), rnd(M, N, seed=4).bfloat16()
+    u = a.float() @ b.float().t() + bias.float()
+    aux = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+    out = ops.gemm(dev(a), dev(b), bias=dev(bias), aux=aux, epilogue=ops.EPI_GELU)
+    torch.testing.assert_close(aux.float().cpu(), u, atol=0.03, rtol=1e-2)
+    torch.testing.assert_close(out.float().cpu(), F.gelu(u), atol=0.03, rtol=1e-2)
+    out = ops.gemm(dev(a), dev(b), bias=dev(bias), residual=dev(res))
+    torch.testing.assert_close(out.float().cpu(), u + res.float(), atol=0.03, rtol=1e-2)
+
+
+def test_colsum_cast_transpose(ops):
+    x = rnd(1037, 200, seed=9)
+    torch.testing.assert_close(ops.colsum(dev(x)).cpu(), x.sum(0), atol=1e-3, rtol=1e-5)
+    xb = x.bfloat16()
+    torch.testing.assert_close(ops.colsum(dev(xb)).cpu(), xb.float().sum(0), atol=1e-3, rtol=1e-5)
+    assert torch.equal(ops.cast(dev(x), torch.bfloat16).cpu(), xb)
+    assert torch.equal(ops.transpose2d(dev(x), torch.bfloat16).cpu(), xb.t().contiguous())
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("D", [128, 768, 1024])
+def test_layernorm(ops, dtype, D):
+    rows = 77
+    x = rnd(rows, D, seed=1, scale=2.0).to(dtype)
+    g = (1 + 0.1 * rnd(D, seed=2)).to(dtype)
+    b = (0.1 * rnd(D, seed=3)).to(dtype)
+    dy = rnd(rows, D, seed=4).to(dtype)
+    add = rnd(rows, D, seed=5).to(dtype)
+    xr = x.float().requires_grad_(True)
+    gr, br = g.float().requires_grad_(True), b.float().requires_grad_(True)
+    yr = F.layer_norm(xr, (D,), gr, br, 1e-12)
+    yr.backward(dy.float())
+    tol = dict(atol=2e-4, rtol=1e-4) if dtype == torch.float32 else dict(atol=0.05, rtol=2e-2)
+    y, mean, rstd = ops.layernorm_fwd(dev(x), dev(g), dev(b), 1e-12)
+    torch.testing.assert_close(y.float().cpu(), yr.detach(), **tol)
+    dg = torch.zeros(D, dtype=torch.float32).cuda()
+    db = torch.zeros(D, dtype=torch.float32).cuda()
+    dx = ops.layernorm_bwd(dev(dy), dev(x), dev(g), mean, rstd, add=dev(add), dgamma=dg, dbeta=db)
+    torch.testing.assert_close(dx.float().cpu(), xr.grad + add.float(), **tol)
+    torch.testing.assert_close(dg.cpu(), gr.grad, atol=5e-3 if dtype == torch.bfloat16 else 2e-4, rtol=1e-3)
+    torch.testing.assert_close(db.cpu(), br.grad, atol=5e-3 if dtype == torch.bfloat16 else 2e-4, rtol=1e-3)
+
+
+# ----------------------------------------------------------------------------- attention
+def ref_attention(qkv, nseq, S, H, scale, bias):
+    """qkv [nseq,S,3D] fp32 (requires_grad), bias [nseq,H,S,S] additive (may hold -inf)."""
+    D = qkv.shape[-1] // 3
+    hd = D // H
+    q, k, v = qkv.split(D, dim=-1)
+    q = q.view(nseq, S, H, hd).transpose(1, 2)
+    k = k.view(nseq, S, H, hd).transpose(1, 2)
+    v = v.view(nseq, S, H, hd).transpose(1, 2)
+    s = q @ k.transpose(-1, -2) * scale + bias
+    p = torch.softmax(s, dim=-1)
+    return (p @ v).transpose(1, 2).reshape(nseq, S, D), torch.logsumexp(s, dim=-1)
+
+
+def make_struct(nseq, S, H, seed):
+    g = torch.Generator().manual_seed(seed)
+    N = S - 1
+    sp = torch.randint(1, 22, (nseq, N, N), generator=g, dtype=torch.int32)
+    ab = torch.zeros(nseq, S, S)
+    far = torch.rand(nseq, N, N, generator=g) < 0.3
+    idx = torch.arange(N)
+    far[:, idx, idx] = False
+    ab[:, 1:, 1:][far] = -math.inf
+    kpad = torch.zeros(nseq, S, dtype=torch.uint8)
+    for b in range(nseq):
+        npad = (b * 3) % max(1, S // 2)
+        if npad:
+            kpad[b, S - npad:] = 1
+            ab[b, :, S - npad:] = -math.inf
+            ab[b, S - npad:, : S - npad] = 0
+            sp[b, N - npad:, :] = 0
+            sp[b, :, N - npad:] = 0
+    table = rnd(64, H, seed=seed + 1, scale=0.5)
+    virt = rnd(H, seed=seed + 2, scale=0.5)
+    return sp, ab, kpad, table, virt
+
+
+def dense_from_struct(sp, ab, kpad, table, virt, H):
+    nseq, S, _ = ab.shape
+    bias = (2 * ab).unsqueeze(1).repeat(1, H, 1, 1)
+    bias[:, :, 1:, 1:] += table[sp.long()].permute(0, 3, 1, 2)
+    bias[:, :, 1:, 0] += virt.view(1, H, 1)
+    bias[:, :, 0, :] += virt.view(1, H, 1)
+    bias = bias.masked_fill(kpad.bool()[:, None, None, :], -math.inf)
+    return bias
+
+
+CASES = [  # (nseq, S, H, hd, mode)
+    (3, 8, 2, 64, "mask"), (2, 14, 12, 64, "none"), (3, 65, 4, 64, "struct"), (2, 104, 3, 64, "mask"),
+    (2, 201, 2, 64, "none"), (2, 33, 4, 64, "dense"), (3, 8, 8, 16, "struct"), (2, 129, 2, 64, "struct"),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nseq,S,H,hd,mode", CASES)
+@pytest.mark.parametrize("time_major", [False, True])
+def test_attention(ops, dtype, nseq, S, H, hd, mode, time_major):
+    if dtype == torch.bfloat16 and hd != 64:
+        pytest.skip("bf16 kernel: head_dim 64 only")
+    if time_major and mode not in ("struct", "dense"):
+        pytest.skip("time-major layout is the graph path")
+    D = H * hd
+    scale = hd ** -0.5
+    qkv = rnd(nseq, S, 3 * D, seed=7).to(dtype)
+    dout = rnd(nseq, S, D, seed=8).to(dtype)
+    kw = {}
+    bias = torch.zeros(nseq, H, S, S)
+    if mode == "mask":
+        km = torch.ones(nseq, S, dtype=torch.uint8)
+        for b in range(nseq):
+            km[b, max(1, S - 1 - 2 * b):] = 0
+        km[0] = 1
+        kw["key_mask"] = dev(km)
+        bias = bias.masked_fill(~km.bool()[:, None, None, :], -math.inf)
+    elif mode == "dense":
+        bias = rnd(nseq, H, S, S, seed=9)
+        bias[:, :, :, S - 2] = -math.inf
+        kw["dense_bias"] = dev(bias)
+    elif mode == "struct":
+        sp, ab, kpad, table, virt = make_struct(nseq, S, H, seed=11)
+        table, virt = table.to(dtype), virt.to(dtype)
+        bias = dense_from_struct(sp, ab, kpad, table.float(), virt.float(), H)
+        kw.update(attn_bias=dev(ab), spatial_pos=dev(sp), sp_table=dev(table), virt=dev(virt), key_pad=dev(kpad))
+    qr = qkv.float().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    oref, lref = ref_attention(qr, nseq, S, H, scale, br)
+    oref.backward(dout.float())
+
+    if time_major:   # rows ordered [S, nseq]
+        q2 = dev(qkv.transpose(0, 1).contiguous().view(S * nseq, 3 * D))
+        d2 = dev(dout.transpose(0, 1).contiguous().view(S * nseq, D))
+        lay = dict(seq_stride=1, pos_stride=nseq)
+    else:
+        q2 = dev(qkv.view(nseq * S, 3 * D))
+        d2 = dev(dout.view(nseq * S, D))
+        lay = dict(seq_stride=S, pos_stride=1)
+    out, lse = ops.attention_fwd(q2, nseq, S, H, scale=scale, **lay, **kw)
+
+    def unlay(t, width):
+        t = t.float().cpu()
+        return t.view(S, nseq, width).transpose(0, 1) if time_major else t.view(nseq, S, width)
+
+    tol = dict(atol=2e-4, rtol=1e-4) if dtype == torch.float32 else dict(atol=0.03, rtol=2e-2)
+    torch.testing.assert_close(unlay(out, D), oref.detach(), **tol)
+    torch.testing.assert_close(lse.cpu(), lref.detach(), atol=2e-4 if dtype == torch.float32 else 0.03, rtol=1e-3)
+
+    extra = {}
+    if mode == "struct":
+        extra = dict(d_sp_table=torch.zeros(64, H, dtype=torch.float32).cuda(),
+                     d_virt=torch.zeros(H, dtype=torch.float32).cuda())
+    dqkv, dbias = ops.attention_bwd(d2, q2, out, lse, nseq, S, H, scale=scale, **lay, **kw,
+                                    want_dense_dbias=(mode == "dense"), **extra)
+    gtol = dict(atol=5e-4, rtol=1e-3) if dtype == torch.float32 else dict(atol=0.06, rtol=5e-2)
+    torch.testing.assert_close(unlay(dqkv, 3 * D), qr.grad, **gtol)
+    if mode == "dense":
+        ref_db = torch.nan_to_num(br.grad, nan=0.0)
+        torch.testing.assert_close(dbias.cpu(), ref_db, **gtol)
+    if mode == "struct":
+        db = torch.nan_to_num(br.grad, nan=0.0)      # [nseq,H,S,S]
+        ref_tab = torch.zeros(64, H)
+        for b in range(nseq):
+            for h in range(H):
+                ref_tab[:, h].index_add_(0, sp[b].long().flatten(), db[b, h, 1:, 1:].flatten())
+        ref_tab[0] = 0                                 # padding_idx row
+        ref_virt = db[:, :, 0, :].sum(dim=(0, 2)) + db[:, :, 1:, 0].sum(dim=(0, 2))
+        torch.testing.assert_close(extra["d_sp_table"].cpu(), ref_tab, atol=gtol["atol"] * 4, rtol=gtol["rtol"])
+        torch.testing.assert_close(extra["d_virt"].cpu(), ref_virt, atol=gtol["atol"] * 8, rtol=gtol["rtol"])
+        dense = ops.graph_attn_bias(dev(ab), dev(sp), dev(table), dev(virt)).cpu()
+        want = dense_from_struct(sp, ab, torch.zeros_like(kpad), table.float(), virt.float(), H)
+        assert torch.equal(torch.isinf(dense), torch.isinf(want))
+        torch.testing.assert_close(torch.nan_to_num(dense, neginf=0.0), torch.nan_to_num(want, neginf=0.0),
+                                   atol=1e-6, rtol=1e-6)
+
+
+# ----------------------------------------------------------------------------- row movers
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_row_ops(ops, dtype):
+    D = 128
+    a, b = rnd(10, D, seed=1).to(dtype), rnd(6, D, seed=2).to(dtype)
+    dst = rnd(12, D, seed=3).to(dtype)
+    di = torch.tensor([3, 0, 7, 11], dtype=torch.int32)
+    ai = torch.tensor([9, 9, 1, 4], dtype=torch.int32)
+    bi = torch.tensor([0, 5, 2, 2], dtype=torch.int32)
+    ref = dst.float().clone()
+    ref[di.long()] = 0.5 * a.float()[ai.long()] + 0.5 * b.float()[bi.long()]
+    got = ops.row_axpby(dev(dst.clone()), 4, di=dev(di), a=dev(a), ai=dev(ai), alpha=0.5, b=dev(b), bi=dev(bi), beta=0.5)
+    torch.testing.assert_close(got.float().cpu(), ref.to(dtype).float(), atol=1e-6, rtol=1e-6)
+    # strided source (token 0 of every 3-token sequence), accumulate into dst rows 2..5
+    ref = dst.float().clone()
+    ref[2:6] += a.float()[0:10:3][:4]
+    got = ops.row_axpby(dev(dst.clone()), 4, d_stride=1, d_off=2, a=dev(a), a_stride=3, a_off=0, accumulate=True)
+    torch.testing.assert_close(got.float().cpu(), ref.to(dtype).float(), atol=1e-2 if dtype == torch.bfloat16 else 1e-6,
+                               rtol=1e-2)
+    # scatter-add with duplicate and skipped rows
+    table = torch.zeros(5, D).cuda()
+    idx = torch.tensor([1, 4, 1, -1, 0, 1], dtype=torch.int32)
+    ops.row_scatter_add(table, dev(idx), dev(b), 6)
+    ref = torch.zeros(5, D)
+    for r, t in enumerate(idx.tolist()):
+        if t >= 0:
+            ref[t] += b.float()[r]
+    torch.testing.assert_close(table.cpu(), ref, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embeddings_and_features(ops, dtype):
+    D, L, M, V = 128, 6, 5, 50
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, V, (M, L), generator=g, dtype=torch.int32)
+    types = torch.randint(0, 2, (M, L), generator=g, dtype=torch.int32)
+    word, pos, typ = rnd(V, D, seed=1).to(dtype), rnd(16, D, seed=2).to(dtype), rnd(2, D, seed=3).to(dtype)
+    nb = 4
+    out = torch.zeros(M * (nb + L), D, dtype=dtype).cuda()
+    ops.bert_embed_sum(dev(ids), dev(types), dev(word), dev(pos), dev(typ), out, out_seq_stride=nb + L, out_off=nb)
+    ref = word.float()[ids.long()] + pos.float()[:L][None] + typ.float()[types.long()]
+    got = out.float().cpu().view(M, nb + L, D)
+    torch.testing.assert_close(got[:, nb:], ref.to(dtype).float(), atol=1e-6, rtol=1e-6)
+    assert float(got[:, :nb].abs().max()) == 0.0
+    # ViT patches
+    I, p, HW = 3, 16, 32
+    img = rnd(I, 3, HW, HW, seed=5)
+    cols = ops.vit_patchify(dev(img), p, dtype)
+    ref = F.unfold(img, kernel_size=p, stride=p).transpose(1, 2).reshape(I * 4, 3 * p * p)
+    torch.testing.assert_close(cols.float().cpu(), ref.to(dtype).float(), atol=1e-6, rtol=1e-6)
+    patches = rnd(I * 4, D, seed=6).to(dtype)
+    cls, ppos = rnd(D, seed=7).to(dtype), rnd(5, D, seed=8).to(dtype)
+    tok = torch.zeros(I * (nb + 5), D, dtype=dtype).cuda()
+    ops.vit_assemble(dev(patches), dev(cls), dev(ppos), tok, I, 4, seq_stride=nb + 5, off=nb)
+    ref = torch.cat([cls.float().expand(I, 1, D), patches.float().view(I, 4, D)], 1) + ppos.float()[None]
+    torch.testing.assert_close(tok.float().cpu().view(I, nb + 5, D)[:, nb:], ref.to(dtype).float(), atol=1e-6, rtol=1e-6)
+    # graph node features
+    B, T = 2, 4
+    src = rnd(7, D, seed=9).to(dtype)
+    node_row = torch.tensor([0, 3, 6, 2, -1, -1], dtype=torch.int32)
+    deg = torch.tensor([2, 3, 1, 1, 0, 0], dtype=torch.int32)
+    ine, oute, tokn = rnd(8, D, seed=10).to(dtype), rnd(8, D, seed=11).to(dtype), rnd(1, D, seed=12).to(dtype)
+    x = ops.graph_node_feature(dev(src), dev(node_row), dev(deg), dev(ine), dev(oute), dev(tokn), B, T)
+    ref = torch.zeros(B, T, D)
+    ref[:, 0] = tokn.float()
+    nr = node_row.view(B, T - 1)
+    for b in range(B):
+        for n in range(T - 1):
+            v = ine.float()[deg.view(B, T - 1)[b, n]] + oute.float()[deg.view(B, T - 1)[b, n]]
+            if nr[b, n] >= 0:
+                v = v + src.float()[nr[b, n]]
+            ref[b, 1 + n] = v
+    torch.testing.assert_close(x.float().cpu().view(B, T, D), ref.to(dtype).float(), atol=1e-6, rtol=1e-6)
+    y = rnd(33, seed=1).to(dtype)
+    torch.testing.assert_close(ops.tanh_fwd(dev(y)).float().cpu(), torch.tanh(y.float()).to(dtype).float(),
+                               atol=1e-6 if dtype == torch.float32 else 1e-2, rtol=1e-2)
+
+
+def test_node_ce_matches_oracle(ops):
+    from oracle import mdt_ref_cpu as R
+    g = torch.Generator().manual_seed(5)
+    M = 40
+    logits = (torch.rand(M, 2, generator=g) * 4 - 2)
+    y_mask = torch.rand(M, generator=g) < 0.4
+    y = (torch.rand(int(y_mask.sum()), generator=g) < 0.4).float()
+    hp = R.hparams(pos_weight=1.5, neg_weight=1.0)
+    lr = logits.clone().requires_grad_(True)
+    loss, counters = R.node_cross_entropy(lr, y, y_mask, hp)
+    loss.backward()
+    rows = torch.nonzero(y_mask).flatten().int()
+    l, c, dl = ops.node_ce(dev(logits), dev(rows), dev(y.int()), 1.0, 1.5)
+    assert abs(float(l.cpu()) - float(loss)) <= 2e-2
+    assert c.cpu().tolist() == [counters["ncorrect"], counters["num_positive_correct"], counters["total_positive"],
+                                counters["num_pred_positive"]]
+    torch.testing.assert_close(dl.cpu(), lr.grad, atol=1e-3, rtol=1e-3)
