@@ -65,9 +65,11 @@ int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int trans_b,
              const void* bias, const void* residual, int64_t ldr,
              void* aux, int64_t ldaux, int split_k);
 
-/* Column sums: out[n] (+)= sum_m X[m,n]  (bias gradients).  out is fp32, accumulated
- * with atomics — zero it first unless accumulating. */
-int mdt_colsum(void* stream, int dtype, int64_t M, int64_t N, const void* X, int64_t ldx, float* out);
+/* Column sums: out[n] (+)= sum_m w[m] * X[m,n]  (bias gradients; w = NULL means 1, otherwise an
+ * int32 row weight — token-type embedding gradient).  out is fp32, accumulated with atomics —
+ * zero it first unless accumulating. */
+int mdt_colsum(void* stream, int dtype, int64_t M, int64_t N, const void* X, int64_t ldx, float* out,
+               const int32_t* row_weight);
 
 /* ------------------------------------------------------------------ LayerNorm
  * y = (x - mean) * rstd * gamma + beta, rows of width D (fairseq LayerNorm eps 1e-5,
@@ -135,17 +137,18 @@ int mdt_graph_attn_bias(void* stream, int dtype, int nseq, int S, int H, const f
 
 /* ------------------------------------------------------------------ row movers
  * dst[di(r), :] = alpha * a[ai(r), :] + beta * b[bi(r), :] (+ dst if accumulate)
- * for r in [0, nrows); an index array may be NULL (identity) and then the matching
- * stride is applied: row = r*stride + offset.  This one kernel is the bottleneck-token
+ * for r in [0, nrows); an index array may be NULL and then a two-level affine map is
+ * applied: row = (r / inner) * stride + r % inner + offset (inner = 1: r*stride + offset).
+ * A negative index skips the row (dst) or contributes zero (a, b).  This one kernel is the bottleneck-token
  * exchange between the text, image and graph token spaces
  * (modules/multigraphormer_graph_encoder.py:339,363-371,425,435;
  *  modules/multi_graphormer_fusion_layer.py:37-66) on precomputed CSR indices — the
  * reference's boolean-mask indexing (implicit nonzero + host sync) is gone.
  */
 int mdt_row_axpby(void* stream, int dtype, int64_t nrows, int D,
-                  void* dst, int64_t ldd, const int32_t* di, int64_t d_stride, int64_t d_off,
-                  const void* a, int64_t lda, const int32_t* ai, int64_t a_stride, int64_t a_off, float alpha,
-                  const void* b, int64_t ldb, const int32_t* bi, int64_t b_stride, int64_t b_off, float beta,
+                  void* dst, int64_t ldd, const int32_t* di, int64_t d_inner, int64_t d_stride, int64_t d_off,
+                  const void* a, int64_t lda, const int32_t* ai, int64_t a_inner, int64_t a_stride, int64_t a_off, float alpha,
+                  const void* b, int64_t ldb, const int32_t* bi, int64_t b_inner, int64_t b_stride, int64_t b_off, float beta,
                   int accumulate);
 /* fp32 table[idx[r], :] += src[r, :]  (embedding backward; atomics).  idx < 0 skipped. */
 int mdt_row_scatter_add_f32(void* stream, int dtype, int64_t nrows, int D, float* table, int64_t ldt,
@@ -167,10 +170,10 @@ int mdt_vit_assemble(void* stream, int dtype, int I, int np, int D, const void* 
 
 /* Graph node features (modules/graphormer_layers.py:39-50) on the padded [B, T] grid:
  * x[b,0] = graph_token; x[b,1+n] = (node_row[b,n] >= 0 ? src[node_row[b,n]] : 0)
- *                                  + in_emb[deg[b,n]] + out_emb[deg[b,n]]. */
+ *                                  + in_emb[in_degree[b,n]] + out_emb[out_degree[b,n]]. */
 int mdt_graph_node_feature(void* stream, int dtype, int B, int T, int D, const void* src, int64_t lds,
-                           const int32_t* node_row, const int32_t* degree, const void* in_emb,
-                           const void* out_emb, const void* graph_token, void* x, int64_t ldx);
+                           const int32_t* node_row, const int32_t* in_degree, const int32_t* out_degree,
+                           const void* in_emb, const void* out_emb, const void* graph_token, void* x, int64_t ldx);
 
 /* Head tail (models/multi_modal_discussion_transformer.py:265-274): logits[m, c] =
  * 0.5 * (cls(pooled_text[m]) + cls(pooled_bn[m])), pooled = tanh(pre-activation) given. */

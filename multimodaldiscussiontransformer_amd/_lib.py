@@ -42,19 +42,19 @@ _SIGS = {
     "mdt_last_error_string": ([], C.c_char_p),
     "mdt_gemm": ([_vp, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _f, _vp, _vp, _i64,
                   _vp, _i64, _i], _i),
-    "mdt_colsum": ([_vp, _i, _i64, _i64, _vp, _i64, _vp], _i),
+    "mdt_colsum": ([_vp, _i, _i64, _i64, _vp, _i64, _vp, _vp], _i),
     "mdt_layernorm_fwd": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _vp, _f, _vp, _i64, _vp, _vp], _i),
     "mdt_layernorm_bwd": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp], _i),
     "mdt_attention_fwd": ([_vp, C.POINTER(AttnFwdArgs)], _i),
     "mdt_attention_bwd": ([_vp, C.POINTER(AttnBwdArgs)], _i),
     "mdt_graph_attn_bias": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
-    "mdt_row_axpby": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _f,
-                       _vp, _i64, _vp, _i64, _i64, _f, _i], _i),
+    "mdt_row_axpby": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _f,
+                       _vp, _i64, _vp, _i64, _i64, _i64, _f, _i], _i),
     "mdt_row_scatter_add_f32": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _vp, _i64, _i64, _i64], _i),
     "mdt_bert_embed_sum": ([_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i64], _i),
     "mdt_vit_patchify": ([_vp, _i, _i, _i, _i, _i, _vp, _vp, _i64], _i),
     "mdt_vit_assemble": ([_vp, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64], _i),
-    "mdt_graph_node_feature": ([_vp, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64], _i),
+    "mdt_graph_node_feature": ([_vp, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64], _i),
     "mdt_tanh_fwd": ([_vp, _i, _i64, _vp, _vp], _i),
     "mdt_tanh_bwd": ([_vp, _i, _i64, _vp, _vp, _vp], _i),
     "mdt_node_ce": ([_vp, _i, _i64, _i, _vp, _vp, _vp, _f, _f, _i, _f, _vp, _vp, _vp], _i),
@@ -110,4 +110,6 @@ def ptr(t) -> int:
 
 
 def stream() -> int:
+    if not torch.cuda.is_available():
+        raise MdtError("no GPU visible: libmdt_hip is the only compute path (there is no CPU fallback)")
     return torch.cuda.current_stream().cuda_stream

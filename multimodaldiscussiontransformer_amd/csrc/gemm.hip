@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile128(GemmParams p) {
 // ------------------------------------------------------------------ helpers
 template <typename TIn, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void colsum_kernel(int64_t M, int64_t N, const TIn* X, int64_t ldx, float* out,
-                                                        int rows_per_block) {
+                                                        int rows_per_block, const int32_t* row_weight) {
   // block = 256 threads: 64 columns x 4 row-lanes; grid.x = column groups, grid.y = row chunks
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
@@ -259,7 +259,10 @@ __global__ __launch_bounds__(BLOCK) void colsum_kernel(int64_t M, int64_t N, con
   const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
   float s = 0.f;
   if (c < N)
-    for (int64_t r = r0 + rl; r < r1; r += 4) s += to_f32(X[r * ldx + c]);
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      const float w = row_weight ? (float)row_weight[r] : 1.f;
+      s += w * to_f32(X[r * ldx + c]);
+    }
   __shared__ float red[4][64];
   red[rl][threadIdx.x & 63] = s;
   __syncthreads();
@@ -365,14 +368,15 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
                               : launch_generic<bf16_t, bf16_t>(st, p, trans_a, trans_b);
 }
 
-extern "C" int mdt_colsum(void* stream, int dtype, int64_t M, int64_t N, const void* X, int64_t ldx, float* out) {
+extern "C" int mdt_colsum(void* stream, int dtype, int64_t M, int64_t N, const void* X, int64_t ldx, float* out,
+                          const int32_t* row_weight) {
   MDT_CHECK_ARG(X && out, "mdt_colsum: null pointer");
   if (M == 0 || N == 0) return MDT_OK;
   const int rows_per_block = 512;
   dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rows_per_block - 1) / rows_per_block));
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MDT_F32) hipLaunchKernelGGL((colsum_kernel<float, 256>), grid, 256, 0, st, M, N, (const float*)X, ldx, out, rows_per_block);
-  else if (dtype == MDT_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t, 256>), grid, 256, 0, st, M, N, (const bf16_t*)X, ldx, out, rows_per_block);
+  if (dtype == MDT_F32) hipLaunchKernelGGL((colsum_kernel<float, 256>), grid, 256, 0, st, M, N, (const float*)X, ldx, out, rows_per_block, row_weight);
+  else if (dtype == MDT_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t, 256>), grid, 256, 0, st, M, N, (const bf16_t*)X, ldx, out, rows_per_block, row_weight);
   else MDT_UNSUPPORTED("mdt_colsum: dtype %d", dtype);
   return check_launch("colsum");
 }

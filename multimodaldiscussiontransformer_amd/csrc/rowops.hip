@@ -11,25 +11,52 @@ template <typename T> struct V16;
 template <> struct V16<float> { static constexpr int N = 4; typedef f32x4 type; };
 template <> struct V16<bf16_t> { static constexpr int N = 8; typedef bf16x8 type; };
 
-__device__ __forceinline__ int64_t pick_row(const int32_t* idx, int64_t stride, int64_t off, int64_t r) {
-  return idx ? (int64_t)idx[r] : r * stride + off;
+__device__ __forceinline__ int64_t pick_row(const int32_t* idx, int64_t inner, int64_t stride, int64_t off, int64_t r) {
+  if (idx) return (int64_t)idx[r];
+  if (inner <= 1) return r * stride + off;
+  const int64_t q = r / inner;
+  return q * stride + (r - q * inner) + off;
+}
+
+// scalar variant for rows that are not 16-byte vectorisable (e.g. the [M, 2] logits)
+template <typename T>
+__global__ __launch_bounds__(256) void row_axpby_scalar_kernel(int64_t nrows, int D, T* dst, int64_t ldd, const int32_t* di,
+                                                               int64_t d_inner, int64_t d_stride, int64_t d_off, const T* a,
+                                                               int64_t lda, const int32_t* ai, int64_t a_inner,
+                                                               int64_t a_stride, int64_t a_off, float alpha, const T* b,
+                                                               int64_t ldb, const int32_t* bi, int64_t b_inner,
+                                                               int64_t b_stride, int64_t b_off, float beta, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= nrows) return;
+  const int64_t dr = pick_row(di, d_inner, d_stride, d_off, r);
+  if (dr < 0) return;
+  const int64_t ar = a ? pick_row(ai, a_inner, a_stride, a_off, r) : -1;
+  const int64_t br = b ? pick_row(bi, b_inner, b_stride, b_off, r) : -1;
+  for (int c = lane; c < D; c += 64) {
+    float v = 0.f;
+    if (ar >= 0) v += alpha * to_f32(a[ar * lda + c]);
+    if (br >= 0) v += beta * to_f32(b[br * ldb + c]);
+    if (accumulate) v += to_f32(dst[dr * ldd + c]);
+    dst[dr * ldd + c] = from_f32<T>(v);
+  }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void row_axpby_kernel(int64_t nrows, int D, T* dst, int64_t ldd, const int32_t* di,
-                                                        int64_t d_stride, int64_t d_off, const T* a, int64_t lda,
-                                                        const int32_t* ai, int64_t a_stride, int64_t a_off, float alpha,
-                                                        const T* b, int64_t ldb, const int32_t* bi, int64_t b_stride,
+                                                        int64_t d_inner, int64_t d_stride, int64_t d_off, const T* a, int64_t lda,
+                                                        const int32_t* ai, int64_t a_inner, int64_t a_stride, int64_t a_off, float alpha,
+                                                        const T* b, int64_t ldb, const int32_t* bi, int64_t b_inner, int64_t b_stride,
                                                         int64_t b_off, float beta, int accumulate) {
   constexpr int VN = V16<T>::N;
   typedef typename V16<T>::type vec;
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= nrows) return;
-  const int64_t dr = pick_row(di, d_stride, d_off, r);
+  const int64_t dr = pick_row(di, d_inner, d_stride, d_off, r);
   if (dr < 0) return;
-  const int64_t ar = a ? pick_row(ai, a_stride, a_off, r) : -1;
-  const int64_t br = b ? pick_row(bi, b_stride, b_off, r) : -1;
+  const int64_t ar = a ? pick_row(ai, a_inner, a_stride, a_off, r) : -1;
+  const int64_t br = b ? pick_row(bi, b_inner, b_stride, b_off, r) : -1;
   for (int c = lane * VN; c < D; c += 64 * VN) {
     vec va, vb, vd, o;
     if (ar >= 0) va = *(const vec*)(a + ar * lda + c);
@@ -118,7 +145,8 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(int I, int np, int D,
 
 template <typename T>
 __global__ __launch_bounds__(256) void graph_node_feature_kernel(int B, int Tn, int D, const T* src, int64_t lds_,
-                                                                 const int32_t* node_row, const int32_t* degree,
+                                                                 const int32_t* node_row, const int32_t* in_degree,
+                                                                 const int32_t* out_degree,
                                                                  const T* in_emb, const T* out_emb, const T* graph_token,
                                                                  T* x, int64_t ldx) {
   const int lane = threadIdx.x & 63;
@@ -133,9 +161,9 @@ __global__ __launch_bounds__(256) void graph_node_feature_kernel(int B, int Tn, 
   }
   const int64_t n = b * (Tn - 1) + (t - 1);
   const int64_t sr = node_row[n];
-  const int64_t dg = degree[n];
+  const int64_t dgi = in_degree[n], dgo = out_degree[n];
   for (int c = lane; c < D; c += 64) {
-    float v = to_f32(in_emb[dg * D + c]) + to_f32(out_emb[dg * D + c]);
+    float v = to_f32(in_emb[dgi * D + c]) + to_f32(out_emb[dgo * D + c]);
     if (sr >= 0) v += to_f32(src[sr * lds_ + c]);
     o[c] = from_f32<T>(v);
   }
@@ -223,19 +251,27 @@ static int vec_ok(int dtype, int D, int64_t ld, const void* p) {
 }
 
 extern "C" int mdt_row_axpby(void* stream, int dtype, int64_t nrows, int D, void* dst, int64_t ldd, const int32_t* di,
-                             int64_t d_stride, int64_t d_off, const void* a, int64_t lda, const int32_t* ai,
-                             int64_t a_stride, int64_t a_off, float alpha, const void* b, int64_t ldb, const int32_t* bi,
-                             int64_t b_stride, int64_t b_off, float beta, int accumulate) {
+                             int64_t d_inner, int64_t d_stride, int64_t d_off, const void* a, int64_t lda, const int32_t* ai,
+                             int64_t a_inner, int64_t a_stride, int64_t a_off, float alpha, const void* b, int64_t ldb,
+                             const int32_t* bi, int64_t b_inner, int64_t b_stride, int64_t b_off, float beta, int accumulate) {
   if (nrows == 0) return MDT_OK;
   MDT_CHECK_ARG(dst, "row_axpby: null dst");
-  if (int e = vec_ok(dtype, D, ldd, dst)) return e;
-  if (a) if (int e = vec_ok(dtype, D, lda, a)) return e;
-  if (b) if (int e = vec_ok(dtype, D, ldb, b)) return e;
+  MDT_CHECK_ARG(dtype == MDT_F32 || dtype == MDT_BF16, "row_axpby: bad dtype %d", dtype);
+  const int vn = dtype == MDT_BF16 ? 8 : 4;
+  bool vec = D % vn == 0 && ldd % vn == 0 && ((uintptr_t)dst & 15) == 0;
+  if (a) vec = vec && lda % vn == 0 && ((uintptr_t)a & 15) == 0;
+  if (b) vec = vec && ldb % vn == 0 && ((uintptr_t)b & 15) == 0;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((nrows + 3) / 4);
-#define K_(T, ...) hipLaunchKernelGGL((row_axpby_kernel<T>), grid, 256, 0, st, nrows, D, (T*)dst, ldd, di, d_stride, d_off, (const T*)a, lda, ai, a_stride, a_off, alpha, (const T*)b, ldb, bi, b_stride, b_off, beta, accumulate)
-  DISPATCH_T(dtype, K_, 0);
-#undef K_
+#define ARGS_(T) nrows, D, (T*)dst, ldd, di, d_inner, d_stride, d_off, (const T*)a, lda, ai, a_inner, a_stride, a_off, alpha, (const T*)b, ldb, bi, b_inner, b_stride, b_off, beta, accumulate
+  if (vec) {
+    if (dtype == MDT_F32) hipLaunchKernelGGL((row_axpby_kernel<float>), grid, 256, 0, st, ARGS_(float));
+    else hipLaunchKernelGGL((row_axpby_kernel<bf16_t>), grid, 256, 0, st, ARGS_(bf16_t));
+  } else {
+    if (dtype == MDT_F32) hipLaunchKernelGGL((row_axpby_scalar_kernel<float>), grid, 256, 0, st, ARGS_(float));
+    else hipLaunchKernelGGL((row_axpby_scalar_kernel<bf16_t>), grid, 256, 0, st, ARGS_(bf16_t));
+  }
+#undef ARGS_
   return check_launch("row_axpby");
 }
 
@@ -289,13 +325,14 @@ extern "C" int mdt_vit_assemble(void* stream, int dtype, int I, int np, int D, c
 }
 
 extern "C" int mdt_graph_node_feature(void* stream, int dtype, int B, int T, int D, const void* src, int64_t lds_,
-                                      const int32_t* node_row, const int32_t* degree, const void* in_emb,
-                                      const void* out_emb, const void* graph_token, void* x, int64_t ldx) {
+                                      const int32_t* node_row, const int32_t* in_degree, const int32_t* out_degree,
+                                      const void* in_emb, const void* out_emb, const void* graph_token, void* x,
+                                      int64_t ldx) {
   if (B == 0) return MDT_OK;
-  MDT_CHECK_ARG(node_row && degree && in_emb && out_emb && graph_token && x, "graph_node_feature: null pointer");
+  MDT_CHECK_ARG(node_row && in_degree && out_degree && in_emb && out_emb && graph_token && x, "graph_node_feature: null pointer");
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)(((int64_t)B * T + 3) / 4);
-#define K_(T_, ...) hipLaunchKernelGGL((graph_node_feature_kernel<T_>), grid, 256, 0, st, B, T, D, (const T_*)src, lds_, node_row, degree, (const T_*)in_emb, (const T_*)out_emb, (const T_*)graph_token, (T_*)x, ldx)
+#define K_(T_, ...) hipLaunchKernelGGL((graph_node_feature_kernel<T_>), grid, 256, 0, st, B, T, D, (const T_*)src, lds_, node_row, in_degree, out_degree, (const T_*)in_emb, (const T_*)out_emb, (const T_*)graph_token, (T_*)x, ldx)
   DISPATCH_T(dtype, K_, 0);
 #undef K_
   return check_launch("graph_node_feature");

@@ -54,6 +54,7 @@ class PackedBatch:
     node_row: torch.Tensor      # i32[B*N]   comment index of (b, n) or -1
     graph_row: torch.Tensor     # i32[M]     b*T + 1 + n of comment m
     degree: torch.Tensor        # i32[B*N]   shifted degree (0 = padding)
+    deg_scatter: torch.Tensor   # i32[B*T]   embedding row fed by graph row r in backward (-1: graph token / padding_idx)
     key_pad: torch.Tensor       # u8[B, T]   1 = padded graph key
     attn_bias: torch.Tensor     # f32[B, T, T]
     spatial_pos: torch.Tensor   # i32[B, N, N]
@@ -90,6 +91,7 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
     node_row = torch.full((B * N,), -1, dtype=torch.int32, pin_memory=pin)
     graph_row = host((M,), torch.int32)
     key_pad = host((B, N + 1), torch.uint8)
+    deg_scatter = torch.full((B, N + 1), -1, dtype=torch.int32, pin_memory=pin)
     img_index, images, ys, y_masks = [], [], [], []
     m = 0
     for b, t in enumerate(trees):
@@ -124,6 +126,8 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
         return None if t is None else t.to(device, non_blocking=non_blocking)
 
     in_deg_t = torch.from_numpy(in_degree)
+    d32 = in_deg_t.int()
+    deg_scatter[:, 1:] = torch.where(d32 > 0, d32, torch.full_like(d32, -1))
     bd = dict(
         idx=torch.arange(B, dtype=torch.int64),
         attn_bias=to(torch.from_numpy(attn_bias)),
@@ -140,9 +144,54 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
     pb = PackedBatch(
         B=B, N=N, M=M, I=int(img_comment.numel()), L=Lq, batched_data=bd,
         ids=to(ids), types=to(types), text_mask=to(tmask), node_row=to(node_row), graph_row=to(graph_row),
-        degree=to(in_deg_t.reshape(-1).int()), key_pad=to(key_pad), attn_bias=bd["attn_bias"],
+        degree=to(in_deg_t.reshape(-1).int()), deg_scatter=to(deg_scatter.view(-1)), key_pad=to(key_pad), attn_bias=bd["attn_bias"],
         spatial_pos=bd["spatial_pos"], img_comment=to(img_comment), images=bd["x_images"],
         label_rows=to(label_rows), targets=to(torch.from_numpy(y.astype(np.int32))), n_labels=int(label_rows.numel()),
     )
     bd["_packed"] = pb                             # lets model(**net_input) find the CSR view
+    return pb
+
+
+def packed_from_batched_data(bd: dict) -> PackedBatch:
+    """Compatibility path: derive the CSR view from a reference-style collated dict (as produced by
+    ``collator``) that is already on the device.  Uses boolean-mask ``nonzero`` (one host sync);
+    ``pack_batch`` avoids it by building the indices on the host."""
+    if "_packed" in bd:
+        return bd["_packed"]
+    mask = bd["x_token_mask"]
+    dev = mask.device
+    B, N = mask.shape
+    Lq = bd["x"].shape[2]
+    T = N + 1
+    flat = mask.reshape(-1)
+    real = torch.nonzero(flat).flatten()
+    M = int(real.numel())
+    node_row = torch.full((B * N,), -1, dtype=torch.int32, device=dev)
+    node_row[real] = torch.arange(M, dtype=torch.int32, device=dev)
+    b_of = torch.div(real, N, rounding_mode="floor")
+    graph_row = (b_of * T + 1 + (real - b_of * N)).to(torch.int32)
+    deg = bd["in_degree"].reshape(B, N).to(torch.int32)
+    deg_scatter = torch.full((B, T), -1, dtype=torch.int32, device=dev)
+    deg_scatter[:, 1:] = torch.where(deg > 0, deg, torch.full_like(deg, -1))
+    key_pad = torch.zeros(B, T, dtype=torch.uint8, device=dev)
+    key_pad[:, 1:] = (~mask).to(torch.uint8)
+    img_idx = bd.get("x_image_indexes")
+    images = bd.get("x_images")
+    img_comment = (torch.nonzero(img_idx).flatten().to(torch.int32) if images is not None
+                   else torch.zeros(0, dtype=torch.int32, device=dev))
+    y_mask = bd.get("y_mask")
+    label_rows = (torch.nonzero(y_mask).flatten().to(torch.int32) if y_mask is not None
+                  else torch.zeros(0, dtype=torch.int32, device=dev))
+    y = bd.get("y")
+    pb = PackedBatch(
+        B=B, N=N, M=M, I=int(img_comment.numel()), L=Lq, batched_data=bd,
+        ids=bd["x"][mask].to(torch.int32).contiguous(), types=bd["x_token_type_ids"][mask].to(torch.int32).contiguous(),
+        text_mask=bd["x_attention_mask"][mask].to(torch.uint8).contiguous(), node_row=node_row, graph_row=graph_row,
+        degree=deg.reshape(-1).contiguous(), deg_scatter=deg_scatter.view(-1), key_pad=key_pad,
+        attn_bias=bd["attn_bias"].float().contiguous(), spatial_pos=bd["spatial_pos"].to(torch.int32).contiguous(),
+        img_comment=img_comment, images=None if images is None else images.float().contiguous(),
+        label_rows=label_rows, targets=(y.flatten().to(torch.int32) if y is not None else label_rows),
+        n_labels=int(label_rows.numel()),
+    )
+    bd["_packed"] = pb
     return pb

@@ -1,0 +1,555 @@
+"""Tape engine: the host-side scheduler of the fused forward / backward.
+
+The reference runs eager PyTorch autograd over ~1000 small ops per step.  Here a step is a
+short *tape* of coarse ops (one per transformer block, exchange, embedding, head), each
+of which launches hand-written HIP kernels through the C ABI and knows its own adjoint.
+The tape owns activation gradients explicitly, which is what lets the bottleneck-token
+exchanges (in-place row writes in the reference: modules/multigraphormer_graph_encoder.py:
+371,425,435; modules/multi_graphormer_fusion_layer.py:63-66) stay sparse row updates in
+backward too, instead of dense zero-filled gradient tensors.
+
+``TapeFunction`` is the single bridge to ``torch.autograd``: a module's public
+``forward`` (same signature as the reference module) wraps its tape-level ``_fwd`` in
+one autograd node.  Parameter gradients are accumulated in fp32 — into ``param.main_grad``
+(persistent, what the RCCL data-parallel hook all-reduces) when present, otherwise into
+temporaries that are handed back to autograd as ordinary ``.grad``s.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+
+class Var:
+    """An activation on the tape: data + lazily created gradient buffer."""
+    __slots__ = ("data", "grad", "needs_grad")
+
+    def __init__(self, data: torch.Tensor, needs_grad: bool = True):
+        self.data = data
+        self.grad: Optional[torch.Tensor] = None
+        self.needs_grad = needs_grad
+
+    @property
+    def rows(self):
+        return self.data.shape[0]
+
+
+class Tape:
+    def __init__(self, use_main_grad: bool = False, on_params_ready: Optional[Callable] = None):
+        self.ops: List[Callable[[], None]] = []
+        self.use_main_grad = use_main_grad
+        self.tmp_grads = {}
+        self.on_params_ready = on_params_ready     # DDP hook: called with the params an op just finished
+
+    # -- gradient plumbing ------------------------------------------------------------
+    def record(self, bwd: Callable[[], None]):
+        self.ops.append(bwd)
+
+    def pgrad(self, p: torch.nn.Parameter) -> Optional[torch.Tensor]:
+        """fp32 accumulation buffer of a parameter, or None when it is frozen."""
+        if p is None or not p.requires_grad:
+            return None
+        if self.use_main_grad:
+            g = getattr(p, "main_grad", None)
+            if g is None:
+                raise RuntimeError("use_main_grad=True but a trainable parameter has no .main_grad buffer")
+            return g
+        g = self.tmp_grads.get(id(p))
+        if g is None:
+            g = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+            self.tmp_grads[id(p)] = g
+        return g
+
+    def grad_buf(self, v: Var) -> torch.Tensor:
+        """Gradient buffer of ``v`` for sparse (row-wise) accumulation; zero-created on first use."""
+        if v.grad is None:
+            v.grad = torch.zeros_like(v.data)
+        return v.grad
+
+    def add_grad(self, v: Var, g: torch.Tensor):
+        """Dense contribution: take ownership of ``g`` or accumulate it."""
+        if not v.needs_grad:
+            return
+        if v.grad is None:
+            v.grad = g
+        else:
+            ops.row_axpby(v.grad, v.grad.shape[0], a=g, accumulate=True)
+
+    def backward(self):
+        while self.ops:
+            self.ops.pop()()
+        self.ops = []
+
+
+# ------------------------------------------------------------------------------------------
+# parameter bundles
+@dataclass
+class BlockParams:
+    """One transformer block.  ``qkv_w`` is the row-concatenation [Wq; Wk; Wv] (3D x D)."""
+    qkv_w: torch.nn.Parameter
+    qkv_b: torch.nn.Parameter
+    o_w: torch.nn.Parameter
+    o_b: torch.nn.Parameter
+    ln1_w: torch.nn.Parameter
+    ln1_b: torch.nn.Parameter
+    fc1_w: torch.nn.Parameter
+    fc1_b: torch.nn.Parameter
+    fc2_w: torch.nn.Parameter
+    fc2_b: torch.nn.Parameter
+    ln2_w: torch.nn.Parameter
+    ln2_b: torch.nn.Parameter
+
+    def all(self):
+        return [self.qkv_w, self.qkv_b, self.o_w, self.o_b, self.ln1_w, self.ln1_b, self.fc1_w, self.fc1_b,
+                self.fc2_w, self.fc2_b, self.ln2_w, self.ln2_b]
+
+
+@dataclass
+class AttnSpec:
+    nseq: int
+    S: int
+    H: int
+    seq_stride: Optional[int] = None
+    pos_stride: int = 1
+    scale: Optional[float] = None
+    key_mask: Optional[torch.Tensor] = None        # u8[nseq,S]
+    dense_bias: Optional[torch.Tensor] = None      # f32[nseq,H,S,S]
+    dense_bias_var: Optional[Var] = None           # gradient sink for dense_bias (module-level API)
+    attn_bias: Optional[torch.Tensor] = None       # f32[nseq,S,S]   structural: {0,-inf} mask
+    spatial_pos: Optional[torch.Tensor] = None     # i32[nseq,S-1,S-1]
+    sp_table: Optional[torch.nn.Parameter] = None  # [num_spatial,H]
+    virt: Optional[torch.nn.Parameter] = None      # [1,H]
+    key_pad: Optional[torch.Tensor] = None         # u8[nseq,S]
+
+    def kwargs(self):
+        return dict(seq_stride=self.seq_stride, pos_stride=self.pos_stride, scale=self.scale, key_mask=self.key_mask,
+                    dense_bias=self.dense_bias, attn_bias=self.attn_bias, spatial_pos=self.spatial_pos,
+                    sp_table=None if self.sp_table is None else self.sp_table.data,
+                    virt=None if self.virt is None else self.virt.data.view(-1), key_pad=self.key_pad)
+
+
+# ------------------------------------------------------------------------------------------
+# helpers
+def _split_k(n_out: int, k_out: int, red: int) -> int:
+    tiles = ((n_out + 127) // 128) * ((k_out + 127) // 128)
+    s = max(1, 1024 // max(1, tiles))
+    return int(max(1, min(s, red // 1024 if red >= 1024 else 1)))
+
+
+def wgrad(tape: Tape, dy: torch.Tensor, x: torch.Tensor, w: torch.nn.Parameter, b: Optional[torch.nn.Parameter]):
+    """dW[N,K] += dY^T X (fp32, split-K atomics) and db[N] += colsum(dY)."""
+    gw = tape.pgrad(w)
+    if gw is not None:
+        ops.gemm(dy, x, trans_a=True, trans_b=True, out=gw.view(dy.shape[1], x.shape[1]), epilogue=ops.EPI_ATOMIC,
+                 split_k=_split_k(dy.shape[1], x.shape[1], dy.shape[0]))
+    gb = tape.pgrad(b) if b is not None else None
+    if gb is not None:
+        ops.colsum(dy, out=gb.view(-1))
+
+
+def _ln_bwd(tape, dy, x, w, b, mean, rstd, add=None):
+    return ops.layernorm_bwd(dy, x, w.data, mean, rstd, add=add, dgamma=tape.pgrad(w), dbeta=tape.pgrad(b))
+
+
+# ------------------------------------------------------------------------------------------
+# ops
+def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre_ln: bool, eps: float) -> Var:
+    """One encoder block (post-LN: HF BertLayer / Graphormer layer; pre-LN: HF ViTLayer or
+    Graphormer with --pre-layernorm).  7 GEMM-class launches + attention + 2 LayerNorms
+    forward; the adjoint below mirrors it with the residual adds folded into epilogues."""
+    xd = x.data
+    kw = spec.kwargs()
+    if not pre_ln:
+        qkv = ops.gemm(xd, P.qkv_w.data, bias=P.qkv_b.data)
+        ctx, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw)
+        t = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xd)
+        a, m1, r1 = ops.layernorm_fwd(t, P.ln1_w.data, P.ln1_b.data, eps)
+        u = torch.empty(a.shape[0], P.fc1_w.shape[0], dtype=a.dtype, device=a.device)
+        h = ops.gemm(a, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU)
+        y = ops.gemm(h, P.fc2_w.data, bias=P.fc2_b.data, residual=a)
+        out, m2, r2 = ops.layernorm_fwd(y, P.ln2_w.data, P.ln2_b.data, eps)
+    else:
+        n1, m1, r1 = ops.layernorm_fwd(xd, P.ln1_w.data, P.ln1_b.data, eps)
+        qkv = ops.gemm(n1, P.qkv_w.data, bias=P.qkv_b.data)
+        ctx, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw)
+        hmid = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xd)
+        n2, m2, r2 = ops.layernorm_fwd(hmid, P.ln2_w.data, P.ln2_b.data, eps)
+        u = torch.empty(n2.shape[0], P.fc1_w.shape[0], dtype=n2.dtype, device=n2.device)
+        f = ops.gemm(n2, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU)
+        out = ops.gemm(f, P.fc2_w.data, bias=P.fc2_b.data, residual=hmid)
+    o = Var(out)
+
+    def attn_bwd(dctx):
+        extra = {}
+        if spec.sp_table is not None:
+            extra = dict(d_sp_table=tape.pgrad(spec.sp_table),
+                         d_virt=None if tape.pgrad(spec.virt) is None else tape.pgrad(spec.virt).view(-1))
+        want_dense = spec.dense_bias_var is not None and spec.dense_bias_var.needs_grad
+        dqkv, dbias = ops.attention_bwd(dctx, qkv, ctx, lse, spec.nseq, spec.S, spec.H, **kw,
+                                        want_dense_dbias=want_dense, **extra)
+        if want_dense:
+            tape.add_grad(spec.dense_bias_var, dbias)
+        return dqkv
+
+    def bwd_post():
+        g = o.grad
+        o.grad = None
+        if g is None:
+            return
+        dy = _ln_bwd(tape, g, y, P.ln2_w, P.ln2_b, m2, r2)
+        wgrad(tape, dy, h, P.fc2_w, P.fc2_b)
+        du = ops.gemm(dy, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_DGELU)
+        wgrad(tape, du, a, P.fc1_w, P.fc1_b)
+        da = ops.gemm(du, P.fc1_w.data, trans_b=True, residual=dy)
+        dt_ = _ln_bwd(tape, da, t, P.ln1_w, P.ln1_b, m1, r1)
+        wgrad(tape, dt_, ctx, P.o_w, P.o_b)
+        dctx = ops.gemm(dt_, P.o_w.data, trans_b=True)
+        dqkv = attn_bwd(dctx)
+        wgrad(tape, dqkv, xd, P.qkv_w, P.qkv_b)
+        if x.needs_grad:
+            tape.add_grad(x, ops.gemm(dqkv, P.qkv_w.data, trans_b=True, residual=dt_))
+        if tape.on_params_ready:
+            tape.on_params_ready(P.all())
+
+    def bwd_pre():
+        g = o.grad
+        o.grad = None
+        if g is None:
+            return
+        wgrad(tape, g, f, P.fc2_w, P.fc2_b)
+        du = ops.gemm(g, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_DGELU)
+        wgrad(tape, du, n2, P.fc1_w, P.fc1_b)
+        dn2 = ops.gemm(du, P.fc1_w.data, trans_b=True)
+        dh = _ln_bwd(tape, dn2, hmid, P.ln2_w, P.ln2_b, m2, r2, add=g)
+        wgrad(tape, dh, ctx, P.o_w, P.o_b)
+        dctx = ops.gemm(dh, P.o_w.data, trans_b=True)
+        dqkv = attn_bwd(dctx)
+        wgrad(tape, dqkv, n1, P.qkv_w, P.qkv_b)
+        if x.needs_grad:
+            dn1 = ops.gemm(dqkv, P.qkv_w.data, trans_b=True)
+            tape.add_grad(x, _ln_bwd(tape, dn1, xd, P.ln1_w, P.ln1_b, m1, r1, add=dh))
+        else:   # LayerNorm parameters still need their gradients
+            dn1 = ops.gemm(dqkv, P.qkv_w.data, trans_b=True)
+            _ln_bwd(tape, dn1, xd, P.ln1_w, P.ln1_b, m1, r1)
+        if tape.on_params_ready:
+            tape.on_params_ready(P.all())
+
+    tape.record(bwd_pre if pre_ln else bwd_post)
+    return o
+
+
+def attention_layer(tape: Tape, x: Var, qkv_w, qkv_b, o_w, o_b, spec: AttnSpec) -> Var:
+    """Bare multi-head self-attention + output projection (modules/multihead_attention.py:91-214)."""
+    xd = x.data
+    kw = spec.kwargs()
+    qkv = ops.gemm(xd, qkv_w.data, bias=None if qkv_b is None else qkv_b.data)
+    ctx, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw)
+    out = ops.gemm(ctx, o_w.data, bias=None if o_b is None else o_b.data)
+    o = Var(out)
+
+    def bwd():
+        g = o.grad
+        o.grad = None
+        if g is None:
+            return
+        wgrad(tape, g, ctx, o_w, o_b)
+        dctx = ops.gemm(g, o_w.data, trans_b=True)
+        extra = {}
+        if spec.sp_table is not None:
+            extra = dict(d_sp_table=tape.pgrad(spec.sp_table),
+                         d_virt=None if tape.pgrad(spec.virt) is None else tape.pgrad(spec.virt).view(-1))
+        want_dense = spec.dense_bias_var is not None and spec.dense_bias_var.needs_grad
+        dqkv, dbias = ops.attention_bwd(dctx, qkv, ctx, lse, spec.nseq, spec.S, spec.H, **kw,
+                                        want_dense_dbias=want_dense, **extra)
+        if want_dense:
+            tape.add_grad(spec.dense_bias_var, dbias)
+        wgrad(tape, dqkv, xd, qkv_w, qkv_b)
+        if x.needs_grad:
+            tape.add_grad(x, ops.gemm(dqkv, qkv_w.data, trans_b=True))
+
+    tape.record(bwd)
+    return o
+
+
+def layernorm(tape: Tape, x: Var, w, b, eps: float) -> Var:
+    y, mean, rstd = ops.layernorm_fwd(x.data, w.data, b.data, eps)
+    o = Var(y)
+
+    def bwd():
+        g = o.grad
+        o.grad = None
+        if g is None:
+            return
+        dx = _ln_bwd(tape, g, x.data, w, b, mean, rstd)
+        tape.add_grad(x, dx)
+
+    tape.record(bwd)
+    return o
+
+
+def bert_embeddings(tape: Tape, ids, types, word, pos, typ) -> Var:
+    """word + position + token-type sum (HF BertEmbeddings before its LayerNorm)."""
+    M, Lq = ids.shape
+    D = word.shape[1]
+    out = torch.empty(M * Lq, D, dtype=word.dtype, device=word.device)
+    ops.bert_embed_sum(ids, types, word.data, pos.data, typ.data, out, out_seq_stride=Lq, out_off=0)
+    o = Var(out)
+
+    def bwd():
+        g = o.grad
+        o.grad = None
+        if g is None:
+            return
+        gw, gp, gt = tape.pgrad(word), tape.pgrad(pos), tape.pgrad(typ)
+        if gw is not None:
+            ops.row_scatter_add(gw, ids.view(-1), g, M * Lq)
+        if gp is not None:
+            ops.colsum(g.view(M, Lq * D), out=gp[:Lq].view(-1))
+        if gt is not None:
+            assert typ.shape[0] == 2, "token-type gradient is implemented for type_vocab_size == 2"
+            tot = ops.colsum(g)
+            one = ops.colsum(g, row_weight=types.view(-1))
+            ops.row_axpby(gt, 1, d_off=1, a=one.view(1, D), accumulate=True)
+            ops.row_axpby(gt, 1, d_off=0, a=tot.view(1, D), b=one.view(1, D), beta=-1.0, accumulate=True)
+
+    tape.record(bwd)
+    return o
+
+
+def vit_embeddings(tape: Tape, images, proj_w, proj_b, cls, pos, patch: int) -> Var:
+    """Conv2d(k = s = patch) as a patch gather + one GEMM, then [CLS] and position add."""
+    I = images.shape[0]
+    D = proj_w.shape[0]
+    g_ = images.shape[-1] // patch
+    npatch = g_ * g_
+    cols = ops.vit_patchify(images, patch, proj_w.dtype)
+    wmat = proj_w.data.view(D, -1)
+    patches = ops.gemm(cols, wmat, bias=proj_b.data)
+    tokens = torch.empty(I * (npatch + 1), D, dtype=proj_w.dtype, device=proj_w.device)
+    ops.vit_assemble(patches, cls.data.view(-1), pos.data.view(npatch + 1, D), tokens, I, npatch,
+                     seq_stride=npatch + 1, off=0)
+    o = Var(tokens)
+
+    def bwd():
+        g = o.grad
+        o.grad = None
+        if g is None:
+            return
+        gw, gb, gc, gp = tape.pgrad(proj_w), tape.pgrad(proj_b), tape.pgrad(cls), tape.pgrad(pos)
+        if gw is not None or gb is not None:
+            dpatch = torch.empty_like(patches)
+            ops.row_axpby(dpatch, I * npatch, a=g, a_inner=npatch, a_stride=npatch + 1, a_off=1)
+            if gw is not None:
+                ops.gemm(dpatch, cols, trans_a=True, trans_b=True, out=gw.view(D, -1), epilogue=ops.EPI_ATOMIC,
+                         split_k=_split_k(D, cols.shape[1], dpatch.shape[0]))
+            if gb is not None:
+                ops.colsum(dpatch, out=gb)
+        if gp is not None:
+            ops.colsum(g.view(I, (npatch + 1) * D), out=gp.view(-1))
+        if gc is not None:
+            ops.colsum(g.view(I, (npatch + 1) * D)[:, :D], out=gc.view(-1))
+
+    tape.record(bwd)
+    return o
+
+
+def expand_sequences(tape: Tape, x: Var, nseq: int, s_in: int, n_front: int, front: Optional[torch.nn.Parameter]) -> Var:
+    """[nseq*s_in, D] → [nseq*(n_front+s_in), D] with ``n_front`` rows prepended to every sequence:
+    the learned bottleneck tokens (``front`` = bottle_neck.weight, modules/multigraphormer_graph_encoder.py:339)
+    or zeros (image sequences, whose bottleneck rows are refreshed before every fusion layer)."""
+    D = x.data.shape[1]
+    S = n_front + s_in
+    out = torch.empty(nseq * S, D, dtype=x.data.dtype, device=x.data.device)
+    ops.row_axpby(out, nseq * s_in, d_inner=s_in, d_stride=S, d_off=n_front, a=x.data)
+    if front is not None:
+        ops.row_axpby(out, nseq * n_front, d_inner=n_front, d_stride=S, d_off=0, a=front.data, a_inner=n_front,
+                      a_stride=0, a_off=0)
+    else:
+        ops.row_axpby(out, nseq * n_front, d_inner=n_front, d_stride=S, d_off=0)
+    o = Var(out)
+
+    def bwd():
+        g = o.grad
+        o.grad = None
+        if g is None:
+            return
+        if front is not None and tape.pgrad(front) is not None:
+            ops.colsum(g.view(nseq, S * D)[:, : n_front * D], out=tape.pgrad(front).view(-1))
+        if x.needs_grad:
+            dx = torch.empty_like(x.data)
+            ops.row_axpby(dx, nseq * s_in, a=g, a_inner=s_in, a_stride=S, a_off=n_front)
+            tape.add_grad(x, dx)
+
+    tape.record(bwd)
+    return o
+
+
+def rows_mix(tape: Tape, dst: Var, src: Var, nrows: int, *, alpha: float, beta: float, d_idx=None, d_map=(1, 1, 0),
+             s_idx=None, s_map=(1, 1, 0)) -> Var:
+    """In place: dst[dr] = alpha * src[sr] + beta * dst[dr] for ``nrows`` row pairs.
+    alpha=1, beta=0 is the reference's ``dst[index] = src[index2]`` assignment; alpha=beta=0.5 the
+    image/text bottleneck average (modules/multi_graphormer_fusion_layer.py:63-66).
+    Adjoint (also in place on the gradient buffers): g_src[sr] += alpha * g_dst[dr]; g_dst[dr] *= beta."""
+    di, ds_, do = d_map
+    si, ss, so = s_map
+    ops.row_axpby(dst.data, nrows, di=d_idx, d_inner=di, d_stride=ds_, d_off=do,
+                  a=src.data, ai=s_idx, a_inner=si, a_stride=ss, a_off=so, alpha=alpha,
+                  b=dst.data if beta != 0.0 else None, bi=d_idx, b_inner=di, b_stride=ds_, b_off=do, beta=beta)
+
+    def bwd():
+        g = dst.grad
+        if g is None:
+            return
+        if src.needs_grad:
+            gs = tape.grad_buf(src)
+            ops.row_axpby(gs, nrows, di=s_idx, d_inner=si, d_stride=ss, d_off=so,
+                          a=g, ai=d_idx, a_inner=di, a_stride=ds_, a_off=do, alpha=alpha, accumulate=True)
+        ops.row_axpby(g, nrows, di=d_idx, d_inner=di, d_stride=ds_, d_off=do,
+                      a=g if beta != 0.0 else None, ai=d_idx, a_inner=di, a_stride=ds_, a_off=do, alpha=beta)
+
+    tape.record(bwd)
+    return dst
+
+
+def graph_node_features(tape: Tape, text: Var, text_row_of_node, in_degree, out_degree, in_emb, out_emb, graph_token,
+                        B: int, T: int, src_rows_of_comment, graph_rows_of_comment, M: int, in_scatter_idx,
+                        out_scatter_idx) -> Var:
+    """modules/graphormer_layers.py:39-50 fused with the masked scatter that builds graph_data
+    (modules/multigraphormer_graph_encoder.py:363-371): node n of tree b reads bottleneck token 0
+    of its comment (row ``text_row_of_node``, -1 = padding node → zeros), both add the degree
+    embeddings.  ``*_scatter_idx`` i32[B*T]: embedding row that graph row r feeds in backward,
+    -1 for the graph token and for padding_idx (degree 0) rows."""
+    x = ops.graph_node_feature(text.data, text_row_of_node, in_degree, out_degree, in_emb.data, out_emb.data,
+                               graph_token.data.view(-1), B, T)
+    o = Var(x)
+    D = x.shape[1]
+
+    def bwd():
+        g = o.grad
+        o.grad = None
+        if g is None:
+            return
+        if text.needs_grad:
+            gt = tape.grad_buf(text)
+            ops.row_axpby(gt, M, di=src_rows_of_comment, a=g, ai=graph_rows_of_comment, accumulate=True)
+        gi, go, gk = tape.pgrad(in_emb), tape.pgrad(out_emb), tape.pgrad(graph_token)
+        if gi is not None:
+            ops.row_scatter_add(gi, in_scatter_idx, g, B * T)
+        if go is not None:
+            ops.row_scatter_add(go, out_scatter_idx, g, B * T)
+        if gk is not None:
+            ops.colsum(g.view(B, T * D)[:, :D], out=gk.view(-1))
+
+    tape.record(bwd)
+    return o
+
+
+def classifier_head(tape: Tape, text: Var, M: int, St: int, nb: int, pool_w, pool_b, cls_w, cls_b) -> Var:
+    """models/multi_modal_discussion_transformer.py:265-274: the SAME pooler (dense + tanh on
+    token 0) and classifier are applied to the text sequence ([CLS], row nb of each comment)
+    and to the bottleneck sequence (bottleneck token 0, row 0); logits are their mean."""
+    D = text.data.shape[1]
+    rows = torch.empty(2 * M, D, dtype=text.data.dtype, device=text.data.device)
+    ops.row_axpby(rows, M, d_off=0, a=text.data, a_stride=St, a_off=nb)
+    ops.row_axpby(rows, M, d_off=M, a=text.data, a_stride=St, a_off=0)
+    pre = ops.gemm(rows, pool_w.data, bias=pool_b.data)
+    pooled = ops.tanh_fwd(pre)
+    l2 = ops.gemm(pooled, cls_w.data, bias=cls_b.data)                       # [2M, C]
+    C = l2.shape[1]
+    logits = torch.empty(M, C, dtype=l2.dtype, device=l2.device)
+    ops.row_axpby(logits, M, a=l2, alpha=0.5, b=l2, b_off=M, beta=0.5)
+    o = Var(logits)
+
+    def bwd():
+        g = o.grad
+        o.grad = None
+        if g is None:
+            return
+        dl2 = torch.empty_like(l2)
+        ops.row_axpby(dl2, M, d_off=0, a=g, alpha=0.5)
+        ops.row_axpby(dl2, M, d_off=M, a=g, alpha=0.5)
+        wgrad(tape, dl2, pooled, cls_w, cls_b)
+        dpooled = ops.gemm(dl2, cls_w.data, trans_b=True)
+        dpre = ops.tanh_bwd(pooled, dpooled)
+        wgrad(tape, dpre, rows, pool_w, pool_b)
+        if text.needs_grad:
+            drows = ops.gemm(dpre, pool_w.data, trans_b=True)
+            gt = tape.grad_buf(text)
+            ops.row_axpby(gt, M, d_stride=St, d_off=nb, a=drows, a_off=0, accumulate=True)
+            ops.row_axpby(gt, M, d_stride=St, d_off=0, a=drows, a_off=M, accumulate=True)
+        if tape.on_params_ready:
+            tape.on_params_ready([pool_w, pool_b, cls_w, cls_b])
+
+    tape.record(bwd)
+    return o
+
+
+def take_rows(tape: Tape, src: Var, nrows: int, s_map=(1, 1, 0), s_idx=None) -> Var:
+    """out[r] = src[row(r)] (e.g. the global embedding = graph-token row of every tree)."""
+    si, ss, so = s_map
+    out = torch.empty(nrows, src.data.shape[1], dtype=src.data.dtype, device=src.data.device)
+    ops.row_axpby(out, nrows, a=src.data, ai=s_idx, a_inner=si, a_stride=ss, a_off=so)
+    o = Var(out)
+
+    def bwd():
+        g = o.grad
+        o.grad = None
+        if g is None or not src.needs_grad:
+            return
+        gs = tape.grad_buf(src)
+        ops.row_axpby(gs, nrows, di=s_idx, d_inner=si, d_stride=ss, d_off=so, a=g, accumulate=True)
+
+    tape.record(bwd)
+    return o
+
+
+# ------------------------------------------------------------------------------------------
+# autograd bridge
+class TapeFunction(torch.autograd.Function):
+    """One autograd node around a whole tape.
+
+    ``TapeFunction.apply(run, use_main_grad, hook, n_in, *tensors)`` where ``tensors`` are the
+    ``n_in`` differentiable tensor inputs followed by every parameter the tape may touch;
+    ``run(tape, *input_vars) -> tuple[Var]``."""
+
+    @staticmethod
+    def forward(ctx, run, use_main_grad, hook, n_in, *tensors):
+        ctx.set_materialize_grads(False)
+        tape = Tape(use_main_grad=use_main_grad, on_params_ready=hook)
+        ins = [Var(t, needs_grad=t.requires_grad) for t in tensors[:n_in]]
+        outs = run(tape, *ins)
+        ctx.tape, ctx.ins, ctx.outs = tape, ins, outs
+        ctx.params = tensors[n_in:]
+        ctx.n_in = n_in
+        return tuple(o.data for o in outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        tape = ctx.tape
+        for o, g in zip(ctx.outs, gouts):
+            if g is not None:
+                g = g.contiguous()
+                o.grad = g if o.grad is None else o.grad + g
+        tape.backward()
+        gin = [v.grad if v.needs_grad else None for v in ctx.ins]
+        if tape.use_main_grad:
+            gp = [None] * len(ctx.params)
+        else:
+            gp = []
+            for p in ctx.params:
+                g = tape.tmp_grads.get(id(p))
+                gp.append(None if g is None else (g if p.dtype == torch.float32 else ops.cast(g, p.dtype)))
+        ctx.tape = ctx.ins = ctx.outs = None
+        return (None, None, None, None, *gin, *gp)
+
+
+def run_tape(run, inputs: Sequence[torch.Tensor], params: Sequence[torch.nn.Parameter], *, use_main_grad=False, hook=None):
+    """Execute ``run`` under the autograd bridge; returns a tuple of output tensors."""
+    probe = inputs[0] if len(inputs) else params[0]
+    if not probe.is_cuda:
+        raise RuntimeError("the mDT HIP path has no CPU fallback: move the module and its inputs to the GPU")
+    return TapeFunction.apply(run, use_main_grad, hook, len(inputs), *inputs, *params)

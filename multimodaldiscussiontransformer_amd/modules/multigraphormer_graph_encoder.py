@@ -1,0 +1,269 @@
+"""Drop-in for mDT/src/modules/multigraphormer_graph_encoder.py
+(``MultiGraphormerGraphEncoder``): the whole fused multimodal graph-attention forward /
+backward of mDT scheduled as one tape of HIP kernels.
+
+What is kept from the reference: constructor arguments, sub-module / parameter names (656
+state-dict keys at the shipped configuration, HF transformers-4.x inner names), the layer
+count rules (``num_fusion_layers + 1`` fusion layers sliced off the *end* of BERT / ViT,
+``ceil(Lf / num_fusion_stack)`` fusion stacks, one more graph stack than fusion stacks of
+which stack ``F-1`` is never executed), and every load-bearing quirk of SURVEY.md §8.
+
+What changed: ragged comments are addressed through CSR index vectors computed by the
+packer (no boolean-mask indexing, no host sync, no ``.cuda()`` uploads inside forward),
+token sequences live in persistent ``[M, nb+L, D]`` / ``[I, nb+P, D]`` buffers, the
+structural attention bias is never materialised, graph tokens stay batch-major.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import engine as E
+from ..data.packer import PackedBatch, packed_from_batched_data
+from ._fused import BertModel, ViTModel
+from .graphormer_graph_encoder_layer import GraphEncoderStack, GraphormerGraphEncoderLayer  # noqa: F401
+from .graphormer_layers import GraphAttnBias, GraphNodeFeature
+from .multi_graphormer_fusion_layer import GraphFusionLayer, GraphFusionStack  # noqa: F401
+from .multihead_attention import MultiheadAttention
+
+
+def init_graphormer_params(module):
+    """multigraphormer_graph_encoder.py:18-39 (only with --apply-graphormer-init)."""
+    def normal_(data):
+        data.copy_(data.cpu().normal_(mean=0.0, std=0.02).to(data.device))
+
+    if isinstance(module, nn.Linear):
+        normal_(module.weight.data)
+        if module.bias is not None:
+            module.bias.data.zero_()
+    if isinstance(module, nn.Embedding):
+        normal_(module.weight.data)
+        if module.padding_idx is not None:
+            module.weight.data[module.padding_idx].zero_()
+    if isinstance(module, MultiheadAttention):
+        normal_(module.qkv_weight.data)
+
+
+BERT_BASE = dict(dim=768, layers=12, heads=12, intermediate=3072, vocab=30522, max_pos=512, type_vocab=2)
+VIT_BASE = dict(dim=768, layers=12, heads=12, intermediate=3072, image_size=224, patch=16)
+
+
+class MultiGraphormerGraphEncoder(nn.Module):
+    # Shapes of the two pre-trained encoders the reference downloads ("bert-base-uncased",
+    # "google/vit-base-patch16-224", :236-245).  There is no network here: the same
+    # architectures are built with random initialisation; override for other sizes.
+    bert_config = BERT_BASE
+    vit_config = VIT_BASE
+
+    def __init__(self, num_atoms: int, num_in_degree: int, num_out_degree: int, num_edges: int, num_spatial: int,
+                 num_edge_dis: int, num_bottle_neck: int, num_fusion_layers: int, edge_type: str, multi_hop_max_dist: int,
+                 num_fusion_stack: int = 1, num_graph_stack: int = 1, num_encoder_layers: int = 12, embedding_dim: int = 768,
+                 ffn_embedding_dim: int = 768, num_attention_heads: int = 32, dropout: float = 0.1,
+                 attention_dropout: float = 0.1, activation_dropout: float = 0.1, layerdrop: float = 0.0,
+                 encoder_normalize_before: bool = False, pre_layernorm: bool = False, apply_graphormer_init: bool = False,
+                 activation_fn: str = "gelu", embed_scale: float = None, freeze_embeddings: bool = False,
+                 n_trans_layers_to_freeze: int = 0, export: bool = False, traceable: bool = False, q_noise: float = 0.0,
+                 qn_block_size: int = 8, freeze_initial_encoders: bool = False, bert_config: Optional[dict] = None,
+                 vit_config: Optional[dict] = None) -> None:
+        super().__init__()
+        if bert_config is not None:
+            self.bert_config = dict(BERT_BASE, **bert_config)
+        if vit_config is not None:
+            self.vit_config = dict(VIT_BASE, **vit_config)
+        if layerdrop > 0 or q_noise > 0 or embed_scale is not None:
+            raise NotImplementedError("layerdrop / quant_noise / embed_scale are unused by mDT and unsupported here")
+        self.dropout_p = dropout
+        self.attention_dropout_p = attention_dropout
+        self.activation_dropout_p = activation_dropout
+        self.layerdrop = layerdrop
+        self.embedding_dim = embedding_dim
+        self.apply_graphormer_init = apply_graphormer_init
+        self.traceable = traceable
+        self.pre_layernorm = pre_layernorm
+        self.num_graph_heads = num_attention_heads
+        num_encoder_layers = num_fusion_layers        # :86 — --encoder-layers is overwritten
+        if self.bert_config["dim"] != embedding_dim or self.vit_config["dim"] != embedding_dim:
+            raise ValueError("graph, BERT and ViT hidden sizes must agree (the reference hard-codes 768 for all three)")
+        self.graph_node_feature = GraphNodeFeature(num_heads=num_attention_heads, num_atoms=num_atoms,
+                                                   num_in_degree=num_in_degree, num_out_degree=num_out_degree,
+                                                   hidden_dim=embedding_dim, n_layers=num_encoder_layers)
+        self.graph_attn_bias = GraphAttnBias(num_heads=num_attention_heads, num_atoms=num_atoms, num_edges=num_edges,
+                                             num_spatial=num_spatial, num_edge_dis=num_edge_dis, edge_type=edge_type,
+                                             multi_hop_max_dist=multi_hop_max_dist, hidden_dim=embedding_dim,
+                                             n_layers=num_encoder_layers)
+        self.embed_scale = embed_scale
+        self.quant_noise = None
+        self.emb_layer_norm = nn.LayerNorm(embedding_dim, eps=1e-5) if encoder_normalize_before else None
+        if pre_layernorm:
+            self.final_layer_norm = nn.LayerNorm(embedding_dim, eps=1e-5)      # constructed, never applied (:124-125)
+        self.layers = nn.ModuleList([])
+        (self.vit_model, self.vit_pooler, vit_other_layers, self.text_model, self.text_pooler, text_other_layers,
+         self.node_classifier, self.text_dropout) = self.build_vit_bert_encoders(num_fusion_layers + 1, attention_dropout,
+                                                                                activation_dropout)
+        self.fusion_layers = nn.ModuleList([])
+        nfs = num_fusion_stack
+        text_groups = [text_other_layers[i * nfs:(i + 1) * nfs] for i in range((len(text_other_layers) + nfs - 1) // nfs)]
+        vit_groups = [vit_other_layers[i * nfs:(i + 1) * nfs] for i in range((len(vit_other_layers) + nfs - 1) // nfs)]
+        self.fusion_layers.extend([GraphFusionStack(t, v, num_bottle_neck, use_projection=True)
+                                   for t, v in zip(text_groups, vit_groups)])
+        self.layers.extend([self.build_graphormer_graph_encoder_layer(
+            num_layers=num_graph_stack, embedding_dim=embedding_dim, ffn_embedding_dim=ffn_embedding_dim,
+            num_attention_heads=num_attention_heads, dropout=dropout, attention_dropout=attention_dropout,
+            activation_dropout=activation_dropout, activation_fn=activation_fn, export=export, q_noise=q_noise,
+            qn_block_size=qn_block_size, pre_layernorm=pre_layernorm) for _ in range(len(self.fusion_layers) + 1)])
+        self.num_bottle_neck = num_bottle_neck
+        self.bottle_neck = nn.Embedding(num_bottle_neck, embedding_dim)
+
+        def set_grad(m, flag):
+            if m is not None:
+                for p in m.parameters():
+                    p.requires_grad = flag
+
+        if freeze_embeddings:
+            raise NotImplementedError("Freezing embeddings is not implemented yet.")
+        if freeze_initial_encoders:      # :223-228 — after the fusion layers were sliced out
+            set_grad(self.text_model, False)
+            set_grad(self.vit_model, False)
+            set_grad(self.node_classifier, True)
+            set_grad(self.text_pooler, True)
+            set_grad(self.vit_pooler, True)
+        for layer in range(n_trans_layers_to_freeze):
+            set_grad(self.layers[layer], False)
+        self.use_main_grad = False
+        self.grad_ready_hook = None
+
+    # ------------------------------------------------------------------ construction
+    def build_vit_bert_encoders(self, num_fusion_layers, attention_dropout, activation_dropout):
+        """Same return tuple as the reference (:233-278).  The last ``num_fusion_layers`` blocks of
+        each encoder become fusion layers; the truncated models keep embeddings, the first
+        blocks, ViT's final LayerNorm and the poolers."""
+        bc, vc = self.bert_config, self.vit_config
+        vit_model = ViTModel(vc["dim"], vc["layers"], vc["heads"], vc["intermediate"], vc["image_size"], vc["patch"])
+        bert_model = BertModel(bc["dim"], bc["layers"], bc["heads"], bc["intermediate"], bc["vocab"], bc["max_pos"],
+                               bc["type_vocab"])
+        if num_fusion_layers == 0:
+            vit_other, bert_other = [], []
+        else:
+            vit_other = list(vit_model.encoder.layer[-num_fusion_layers:])
+            vit_model.encoder.layer = vit_model.encoder.layer[:-num_fusion_layers]
+            bert_other = list(bert_model.encoder.layer[-num_fusion_layers:])
+            bert_model.encoder.layer = bert_model.encoder.layer[:-num_fusion_layers]
+        node_classifier = nn.Linear(bc["dim"], 2)       # BertForSequenceClassification.classifier, num_labels = 2
+        nn.init.normal_(node_classifier.weight, 0.0, 0.02)
+        nn.init.zeros_(node_classifier.bias)
+        bert_dropout = nn.Dropout(activation_dropout)
+        return (vit_model, vit_model.pooler, vit_other, bert_model, bert_model.pooler, bert_other, node_classifier,
+                bert_dropout)
+
+    def build_graphormer_graph_encoder_layer(self, embedding_dim, ffn_embedding_dim, num_attention_heads, dropout,
+                                             attention_dropout, activation_dropout, activation_fn, export, q_noise,
+                                             qn_block_size, pre_layernorm, num_layers=1):
+        return GraphEncoderStack(num_layers=num_layers, embedding_dim=embedding_dim, ffn_embedding_dim=ffn_embedding_dim,
+                                 num_attention_heads=num_attention_heads, dropout=dropout,
+                                 attention_dropout=attention_dropout, activation_dropout=activation_dropout,
+                                 activation_fn=activation_fn, export=export, q_noise=q_noise, qn_block_size=qn_block_size,
+                                 pre_layernorm=pre_layernorm)
+
+    # ------------------------------------------------------------------ index helpers
+    def _indices(self, pb: PackedBatch):
+        nb = self.num_bottle_neck
+        St = nb + pb.L
+        key = ("enc_idx", St)
+        if key in pb.extras:
+            return pb.extras[key]
+        dev = pb.ids.device
+        np_ = (self.vit_config["image_size"] // self.vit_config["patch"]) ** 2
+        Sv = nb + np_ + 1
+        ones = torch.ones(pb.M, nb, dtype=torch.uint8, device=dev)
+        j = torch.arange(nb, device=dev, dtype=torch.int32)
+        idx = dict(
+            St=St, Sv=Sv, P=np_ + 1,
+            fusion_mask=torch.cat([ones, pb.text_mask], dim=1).contiguous(),
+            text_row_of_node=torch.where(pb.node_row >= 0, pb.node_row * St, pb.node_row).contiguous(),
+            bn0_rows=(torch.arange(pb.M, device=dev, dtype=torch.int32) * St).contiguous(),
+            img_text_bn_rows=(pb.img_comment[:, None] * St + j[None]).reshape(-1).contiguous(),
+            vit_bn_rows=(torch.arange(pb.I, device=dev, dtype=torch.int32)[:, None] * Sv + j[None]).reshape(-1).contiguous(),
+        )
+        pb.extras[key] = idx
+        return idx
+
+    # ------------------------------------------------------------------ tape-level forward
+    def _fwd(self, tape, pb: PackedBatch):
+        """→ (text buffer Var [M*(nb+L), D], global embedding Var [B, D])."""
+        if self.training and (self.dropout_p > 0 or self.attention_dropout_p > 0 or self.activation_dropout_p > 0):
+            raise NotImplementedError("dropout > 0 in training mode is not implemented in the HIP path yet; "
+                                      "build the model with --dropout 0 --attention-dropout 0 --act-dropout 0")
+        nb = self.num_bottle_neck
+        ix = self._indices(pb)
+        St, Sv, P = ix["St"], ix["Sv"], ix["P"]
+        M, Lq, I, B, T = pb.M, pb.L, pb.I, pb.B, pb.T
+        tm, vm = self.text_model, self.vit_model
+        e = tm.embeddings
+        emb = E.bert_embeddings(tape, pb.ids, pb.types, e.word_embeddings.weight, e.position_embeddings.weight,
+                                e.token_type_embeddings.weight)
+        text = E.layernorm(tape, emb, e.LayerNorm.weight, e.LayerNorm.bias, tm.eps)
+        spec0 = E.AttnSpec(nseq=M, S=Lq, H=tm.heads, key_mask=pb.text_mask)
+        for layer in tm.encoder.layer:
+            text = E.transformer_block(tape, text, layer.block_params(), spec0, pre_ln=False, eps=tm.eps)
+        vit = None
+        if I > 0:
+            ve = vm.embeddings
+            v = E.vit_embeddings(tape, pb.images, ve.patch_embeddings.projection.weight, ve.patch_embeddings.projection.bias,
+                                 ve.cls_token, ve.position_embeddings, vm.patch)
+            specv = E.AttnSpec(nseq=I, S=P, H=vm.heads)
+            for layer in vm.encoder.layer:
+                v = E.transformer_block(tape, v, layer.block_params(), specv, pre_ln=True, eps=vm.eps)
+            v = E.layernorm(tape, v, vm.layernorm.weight, vm.layernorm.bias, vm.eps)      # quirk 5: final LN mid-network
+            vit = E.expand_sequences(tape, v, I, P, nb, None)
+        text = E.expand_sequences(tape, text, M, Lq, nb, self.bottle_neck.weight)
+        fargs = (M, St, I, Sv, ix["fusion_mask"], ix["img_text_bn_rows"], ix["vit_bn_rows"])
+        text, vit = self.fusion_layers[0]._fwd(tape, text, vit, *fargs)
+        gnf = self.graph_node_feature
+        x = E.graph_node_features(tape, text, ix["text_row_of_node"], pb.degree, pb.degree, gnf.in_degree_encoder.weight,
+                                  gnf.out_degree_encoder.weight, gnf.graph_token.weight, B, T, ix["bn0_rows"], pb.graph_row,
+                                  M, pb.deg_scatter, pb.deg_scatter)
+        if self.emb_layer_norm is not None:
+            x = E.layernorm(tape, x, self.emb_layer_norm.weight, self.emb_layer_norm.bias, 1e-5)
+        gab = self.graph_attn_bias
+        hd = self.embedding_dim // self.num_graph_heads
+        gspec = E.AttnSpec(nseq=B, S=T, H=self.num_graph_heads, scale=hd ** -0.5, attn_bias=pb.attn_bias,
+                           spatial_pos=pb.spatial_pos, sp_table=gab.spatial_pos_encoder.weight,
+                           virt=gab.graph_token_virtual_distance.weight, key_pad=pb.key_pad)
+        F = len(self.fusion_layers)
+        for st in range(F - 1):                       # zip(self.layers, self.fusion_layers[1:])  (:413)
+            x = self.layers[st]._fwd(tape, x, gspec)
+            # bottle_neck[:, 0, :] = x[mask]  (:425)
+            E.rows_mix(tape, text, x, M, alpha=1.0, beta=0.0, d_map=(1, St, 0), s_idx=pb.graph_row)
+            text, vit = self.fusion_layers[st + 1]._fwd(tape, text, vit, *fargs)
+            # x[mask] = bottle_neck[:, 0, :]  (:435)
+            E.rows_mix(tape, x, text, M, alpha=1.0, beta=0.0, d_idx=pb.graph_row, s_map=(1, St, 0))
+        x = self.layers[-1]._fwd(tape, x, gspec)       # layers[F]; layers[F-1] is never executed (quirk 3)
+        glob = E.take_rows(tape, x, B, s_map=(1, T, 0))
+        return text, glob
+
+    def live_parameters(self):
+        seen, out = set(), []
+        for p in self.parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+        return out
+
+    def forward(self, batched_data, last_state_only: bool = False, token_embeddings: Optional[torch.Tensor] = None,
+                attn_mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """→ (text [M, L, D], bottle_neck [M, nb, D], global_embedding [B, D]) as the reference (:464)."""
+        if attn_mask is not None or token_embeddings is not None:
+            raise NotImplementedError("attn_mask / token_embeddings are unused by mDT and unsupported")
+        pb = packed_from_batched_data(batched_data)
+        nb = self.num_bottle_neck
+
+        def run(tape):
+            text, glob = self._fwd(tape, pb)
+            return text, glob
+
+        buf, glob = E.run_tape(run, [], self.live_parameters(), use_main_grad=self.use_main_grad, hook=self.grad_ready_hook)
+        D = buf.shape[1]
+        buf = buf.view(pb.M, nb + pb.L, D)
+        return buf[:, nb:], buf[:, :nb], glob

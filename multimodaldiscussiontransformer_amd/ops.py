@@ -53,11 +53,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
     return out
 
 
-def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[n] += sum_m x[m, n] (fp32, atomics)."""
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, row_weight=None) -> torch.Tensor:
+    """out[n] += sum_m w[m] * x[m, n] (fp32, atomics); w int32 or None."""
     if out is None:
         out = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
-    check(lib.mdt_colsum(stream(), dt(x), x.shape[0], x.shape[1], ptr(x), _2d(x), ptr(out)), "mdt_colsum")
+    assert row_weight is None or (row_weight.dtype == torch.int32 and row_weight.numel() == x.shape[0])
+    check(lib.mdt_colsum(stream(), dt(x), x.shape[0], x.shape[1], ptr(x), _2d(x), ptr(out), ptr(row_weight)),
+          "mdt_colsum")
     return out
 
 
@@ -150,15 +152,15 @@ def graph_attn_bias(attn_bias, spatial_pos, sp_table, virt):
     return out
 
 
-def row_axpby(dst, nrows, *, di=None, d_stride=1, d_off=0, a=None, ai=None, a_stride=1, a_off=0, alpha=1.0,
-              b=None, bi=None, b_stride=1, b_off=0, beta=1.0, accumulate=False):
+def row_axpby(dst, nrows, *, di=None, d_inner=1, d_stride=1, d_off=0, a=None, ai=None, a_inner=1, a_stride=1, a_off=0,
+              alpha=1.0, b=None, bi=None, b_inner=1, b_stride=1, b_off=0, beta=1.0, accumulate=False):
     """dst[di(r)] = alpha*a[ai(r)] + beta*b[bi(r)] (+ dst); 2-D row-major tensors, int32 index vectors."""
     D = dst.shape[1]
     for t in (di, ai, bi):
         assert t is None or (t.dtype == torch.int32 and t.is_contiguous())
-    check(lib.mdt_row_axpby(stream(), dt(dst), nrows, D, ptr(dst), _2d(dst), ptr(di), d_stride, d_off,
-                            ptr(a), _2d(a) if a is not None else 0, ptr(ai), a_stride, a_off, float(alpha),
-                            ptr(b), _2d(b) if b is not None else 0, ptr(bi), b_stride, b_off, float(beta),
+    check(lib.mdt_row_axpby(stream(), dt(dst), nrows, D, ptr(dst), _2d(dst), ptr(di), d_inner, d_stride, d_off,
+                            ptr(a), _2d(a) if a is not None else 0, ptr(ai), a_inner, a_stride, a_off, float(alpha),
+                            ptr(b), _2d(b) if b is not None else 0, ptr(bi), b_inner, b_stride, b_off, float(beta),
                             int(accumulate)), "mdt_row_axpby")
     return dst
 
@@ -194,13 +196,13 @@ def vit_assemble(patches, cls, pos, tokens, I, npatch, *, seq_stride, off):
     return tokens
 
 
-def graph_node_feature(src, node_row, degree, in_emb, out_emb, graph_token, B, T):
+def graph_node_feature(src, node_row, in_degree, out_degree, in_emb, out_emb, graph_token, B, T):
     D = in_emb.shape[1]
     x = torch.empty(B * T, D, dtype=in_emb.dtype, device=in_emb.device)
-    assert node_row.dtype == torch.int32 and degree.dtype == torch.int32
+    assert node_row.dtype == torch.int32 and in_degree.dtype == torch.int32 and out_degree.dtype == torch.int32
     check(lib.mdt_graph_node_feature(stream(), dt(x), B, T, D, ptr(src), _2d(src) if src is not None else 0,
-                                     ptr(node_row), ptr(degree), ptr(in_emb), ptr(out_emb), ptr(graph_token), ptr(x),
-                                     _2d(x)), "mdt_graph_node_feature")
+                                     ptr(node_row), ptr(in_degree), ptr(out_degree), ptr(in_emb), ptr(out_emb),
+                                     ptr(graph_token), ptr(x), _2d(x)), "mdt_graph_node_feature")
     return x
 
 

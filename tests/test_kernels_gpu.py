@@ -335,7 +335,7 @@ def test_embeddings_and_features(ops, dtype):
     node_row = torch.tensor([0, 3, 6, 2, -1, -1], dtype=torch.int32)
     deg = torch.tensor([2, 3, 1, 1, 0, 0], dtype=torch.int32)
     ine, oute, tokn = rnd(8, D, seed=10).to(dtype), rnd(8, D, seed=11).to(dtype), rnd(1, D, seed=12).to(dtype)
-    x = ops.graph_node_feature(dev(src), dev(node_row), dev(deg), dev(ine), dev(oute), dev(tokn), B, T)
+    x = ops.graph_node_feature(dev(src), dev(node_row), dev(deg), dev(deg), dev(ine), dev(oute), dev(tokn), B, T)
     ref = torch.zeros(B, T, D)
     ref[:, 0] = tokn.float()
     nr = node_row.view(B, T - 1)
