@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py — discussion-tree comments/sec, forward + backward, of the mDT hot path on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic discussion trees that is
+already resident in HBM: encoder (BERT / ViT blocks, bottleneck fusion, Graphormer attention)
+→ head → weighted CE → backward → (N > 1) RCCL gradient all-reduce overlapped with backward.
+Workload (BASELINE.json configs[1]): mDT-base — BERT-base + ViT-B/16 split 6 + 6, 6 executed
+graph layers, D 768, 12 heads, nb 4, L 100 — on 32 bushy 64-comment trees per GPU with 25 % image
+comments, bf16 activations / weights, fp32 softmax, LayerNorm statistics and gradient arena.
+Weak scaling: every rank processes its own 32 trees, no data-path collective except the
+gradient all-reduce.
+
+Rank 0 prints ONE JSON line (contract in the task description) carrying
+  roofline      the dominant kernel (bf16 MFMA tile GEMM): algorithmic FLOPs of its launches /
+                their summed duration, measured live with HIP events on the launch stream
+                during the timed steps; peak = 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md)
+  cpu_baseline  the oracle (CPU restatement of the reference math, fp32, torch CPU) timed on
+                this box's host cores on a bounded sample of the same workload (rank 0, N = 1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0
+
+
+def base_args(a):
+    return SimpleNamespace(
+        num_atoms=512 * 9, num_in_degree=512, num_out_degree=512, num_edges=512 * 3, num_spatial=512, num_edge_dis=128,
+        edge_type="multi_hop", multi_hop_max_dist=5, num_bottleneck_tokens=4, num_fusion_layers=a.num_fusion_layers,
+        num_fusion_stack=1, num_graph_stack=1, encoder_layers=4, encoder_embed_dim=768, encoder_ffn_embed_dim=768,
+        encoder_attention_heads=12, dropout=0.0, attention_dropout=0.0, act_dropout=0.0, encoder_normalize_before=True,
+        pre_layernorm=False, apply_graphormer_init=False, activation_fn="gelu",
+        freeze_initial_encoders=a.freeze_initial_encoders, share_encoder_input_output_embed=False, max_nodes=10000,
+        num_classes=1)
+
+
+def flops_per_comment(L=100, nb=4, P=197, D=768, F=3072, Lb=6, Lf=6, G=6, N=64, Fg=768, rho=0.25, patch=16):
+    """Algorithmic forward FLOPs per comment."""
+    def enc(S):
+        return 8 * S * D * D + 4 * S * D * F + 4 * S * S * D
+    text = Lb * enc(L) + Lf * enc(L + nb)
+    image = 2 * (P - 1) * (3 * patch * patch) * D + Lb * enc(P) + Lf * enc(P + nb)
+    T = N + 1
+    graph_tree = G * (8 * T * D * D + 4 * T * D * Fg + 4 * T * T * D)
+    head = 2 * (2 * D * D + 4 * D)
+    return text + rho * image + graph_tree / N + head
+
+
+class GemmTimer:
+    """HIP-event timing of every mdt_gemm launch on the current stream (tile kernel only)."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+
+    def install(self):
+        from multimodaldiscussiontransformer_amd import ops
+        from multimodaldiscussiontransformer_amd import engine
+        raw = ops.gemm
+        timer = self
+
+        def timed(a, b, *, trans_a=False, trans_b=False, **kw):
+            if not timer.enabled or a.dtype != torch.bfloat16:
+                return raw(a, b, trans_a=trans_a, trans_b=trans_b, **kw)
+            M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+            N = b.shape[1] if trans_b else b.shape[0]
+            tile = (N % 128 == 0) and (K % 64 == 0 or (trans_a and trans_b))
+            if not tile:
+                return raw(a, b, trans_a=trans_a, trans_b=trans_b, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = raw(a, b, trans_a=trans_a, trans_b=trans_b, **kw)
+            e.record()
+            timer.records.append((s, e, 2.0 * M * N * K))
+            return out
+
+        ops.gemm = timed
+        engine.ops.gemm = timed
+
+    def summary(self):
+        if not self.records:
+            return None
+        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        return dict(launches=len(self.records), total_ms=ms, flops=fl, tflops=fl / (ms * 1e-3) / 1e12,
+                    avg_us=ms * 1e3 / len(self.records))
+
+
+def cpu_baseline(args):
+    """Oracle (CPU restatement) fwd+bwd on a bounded sample; comments/s on the host cores."""
+    from multimodaldiscussiontransformer_amd import synthetic
+    from oracle import mdt_ref_cpu as R
+    from oracle import structure as S
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    hp = R.hparams(dim=768, enc_heads=12, graph_heads=12, enc_ffn=3072, graph_ffn=768, text_layers=12, vit_layers=12,
+                   num_fusion_layers=args.num_fusion_layers, num_fusion_stack=1, num_graph_stack=1, num_bottleneck=4,
+                   pos_weight=1.5, neg_weight=1.0)
+    n_trees, n_nodes = 2, 16
+    trees = synthetic.make_trees(n_trees, n_nodes, seed=4321, seq_len=100, image_frac=0.25, image_size=224)
+    batch = R.to_torch_batch(S.collate(trees, 5))
+    g = torch.Generator().manual_seed(0)
+    W = {n: (torch.randn(s, generator=g) * 0.02).requires_grad_(True) for n, s in R.param_shapes(hp).items()}
+    t0 = time.time()
+    logits, _ = R.model_forward(W, hp, batch)
+    loss, _ = R.node_cross_entropy(logits, batch["y"], batch["y_mask"], hp)
+    loss.backward()
+    dt = time.time() - t0
+    m = n_trees * n_nodes
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(value=m / dt, unit="comments/s", cores=ncores, kind="port",
+                sample=f"oracle (torch CPU fp32 restatement) fwd+bwd, {n_trees} trees x {n_nodes} comments, "
+                       f"25% image comments, mDT-base, 1 pass, {dt:.1f} s on {model}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--trees", type=int, default=32, help="trees per GPU")
+    ap.add_argument("--nodes", type=int, default=64)
+    ap.add_argument("--image-frac", type=float, default=0.25)
+    ap.add_argument("--num_fusion_layers", type=int, default=5)
+    ap.add_argument("--freeze_initial_encoders", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-timer", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from multimodaldiscussiontransformer_amd import synthetic
+    from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
+    from multimodaldiscussiontransformer_amd.data.packer import pack_batch
+    from multimodaldiscussiontransformer_amd.ddp import DataParallel
+    from multimodaldiscussiontransformer_amd.models import GraphormerModel
+
+    timer = GemmTimer()
+    if not args.no_gemm_timer:
+        timer.install()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(1234)                      # same random-init weights on every rank
+    model = GraphormerModel.build_model(base_args(args), task=None).cuda().to(dtype)
+    model.train()
+    dp = DataParallel(model)
+    dp.broadcast_parameters()
+    crit = GraphPredictionNodeCrossEntropy(None, positive_weight=1.5, negative_weight=1.0)
+
+    nbatch = 2
+    batches = []
+    for i in range(nbatch):
+        trees = synthetic.make_trees(args.trees, args.nodes, seed=1234 + rank * 1000 + i, seq_len=100,
+                                     image_frac=args.image_frac, image_size=224)
+        batches.append(pack_batch(trees, spatial_pos_max=5))
+    torch.cuda.synchronize()
+    comments_per_step = batches[0].M
+    scal = torch.zeros(6, dtype=torch.float32, device="cuda")
+
+    def step(i):
+        pb = batches[i % nbatch]
+        dp.zero_grad()
+        sample = {"nsamples": pb.B, "net_input": {"batched_data": pb.batched_data}}
+        loss, sample_size, log = crit(model, sample)
+        loss.backward()
+        scal[0] = loss.detach().float()
+        scal[1] = float(sample_size)
+        scal[2:6] = torch.stack([log["ncorrect"], log["num_positive_correct"], log["total_positive"],
+                                 log["num_pred_positive"]]).float()
+        dp.finish_backward(scal)
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    timer.enabled = not args.no_gemm_timer
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    total_comments = comments_per_step * world * args.steps
+    value = total_comments / dt
+
+    if rank == 0:
+        fpc = flops_per_comment(Lb=12 - (args.num_fusion_layers + 1), Lf=args.num_fusion_layers + 1,
+                                G=args.num_fusion_layers + 1, N=args.nodes, rho=args.image_frac)
+        gs = timer.summary()
+        roofline = None
+        if gs:
+            roofline = dict(bound="mfma", kernel="gemm_bf16_tile128", achieved=round(gs["tflops"], 1),
+                            peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(gs["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4),
+                            traffic=None, launches=gs["launches"], avg_launch_us=round(gs["avg_us"], 1),
+                            share_of_step=round(gs["total_ms"] * 1e-3 / dt, 3))
+        out = {
+            "metric": "discussion-tree comments/sec fwd+bwd", "value": round(value, 1), "unit": "comments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "mDT-base (BERT-base + ViT-B/16 split 6+6, 6 executed graph layers, D768 H12 nb4 L100), "
+                                   f"{args.trees} bushy {args.nodes}-comment trees per GPU, {int(args.image_frac * 100)}% image comments, "
+                                   "random-init weights, dropout 0, no optimizer step",
+                       "trees_per_gpu": args.trees, "comments_per_step_per_gpu": comments_per_step,
+                       "parallelism": f"dp{world}", "frozen_initial_encoders": bool(args.freeze_initial_encoders)},
+            "model_tflops": round(value * 3 * fpc / 1e12, 1),
+            "model_frac_of_bf16_peak": round(value * 3 * fpc / 1e12 / (BF16_DENSE_PEAK_TFLOPS * world), 4),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

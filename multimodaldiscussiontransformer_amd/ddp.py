@@ -1,0 +1,160 @@
+"""Data-parallel gradient exchange for mDT: discussion trees are sharded across the GPUs of one
+node (one process per GPU), the only exchange step is the sum-all-reduce of parameter
+gradients (RCCL over xGMI through ``torch.distributed``, backend "nccl" on ROCm) plus one
+tiny all-reduce of the logging scalars.
+
+The reference has no DDP code (FairSeq's trainer does it, ``--distributed-world-size``,
+mDT/experiments/hateful_discussions/run_train.sh:52); FairSeq's convention is reproduced:
+gradients are summed over ranks and divided by the global sample size (the criterion uses
+``reduction="sum"`` and summable logging outputs, criterions/hatespeech_loss.py:116,175-182).
+
+Design for xGMI (point-to-point links, ring collectives are per-link bound): few, large
+buckets.  All trainable gradients live in ONE flat fp32 arena (``GraphormerModel.
+prepare_main_grads``); after the first backward the arena is re-laid-out in the order the tape
+finished each parameter group, so every bucket is a contiguous slice that becomes final
+early — it is all-reduced in place on a side stream while backward continues (no copies, no
+per-parameter hooks, statically-dead parameters never enter the arena's hot prefix).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradientBucketer:
+    """Backend-agnostic core (works on CPU tensors with gloo — that is how it is tested)."""
+
+    def __init__(self, params: List[torch.nn.Parameter], flat: torch.Tensor, bucket_bytes: int = 64 << 20,
+                 process_group=None, comm_stream: Optional["torch.cuda.Stream"] = None):
+        self.params = [p for p in params if p.requires_grad]
+        self.flat = flat
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.pg = process_group
+        self.comm_stream = comm_stream
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.order_observed: List[int] = []       # ids in completion order (first backward)
+        self.layout_final = False
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._assign_views(self.params)
+        self.reset()
+
+    # -- layout -------------------------------------------------------------------------
+    def _assign_views(self, ordered):
+        off = 0
+        self.slots = []
+        for p in ordered:
+            n = p.numel()
+            p.main_grad = self.flat[off:off + n].view(p.shape)
+            self.slots.append((id(p), off, n))
+            off += n
+        assert off == self.flat.numel()
+        self._pos = {pid: i for i, (pid, _, _) in enumerate(self.slots)}
+
+    def finalize_layout(self):
+        """Re-lay the arena out in observed completion order (parameters never reported go last).
+        Gradient values already in the arena are carried over to the new positions."""
+        seen = set()
+        ordered = []
+        for pid in self.order_observed:
+            if pid not in seen and pid in self._index:
+                seen.add(pid)
+                ordered.append(self.params[self._index[pid]])
+        ordered += [p for p in self.params if id(p) not in seen]
+        old = self.flat.clone()
+        old_slots = {pid: (off, n) for pid, off, n in self.slots}
+        self._assign_views(ordered)
+        for p in ordered:
+            off, n = old_slots[id(p)]
+            p.main_grad.view(-1).copy_(old[off:off + n])
+        self.layout_final = True
+        self.reset()
+
+    # -- per-step state -------------------------------------------------------------------
+    def reset(self):
+        self.ready = [False] * len(self.slots)
+        self.cursor = 0            # slots [0, cursor) are final
+        self.launched = 0          # elements [0, launched) already handed to all_reduce
+        self.handles = []
+
+    def on_params_ready(self, params):
+        """Tape hook: the gradients of ``params`` are final for this step."""
+        for p in params:
+            i = self._pos.get(id(p))
+            if i is None:
+                continue
+            if not self.layout_final:
+                self.order_observed.append(id(p))
+            self.ready[i] = True
+        while self.cursor < len(self.slots) and self.ready[self.cursor]:
+            self.cursor += 1
+        if self.world > 1 and self.layout_final:
+            end = self.slots[self.cursor - 1][1] + self.slots[self.cursor - 1][2] if self.cursor else 0
+            if end - self.launched >= self.bucket_elems:
+                self._launch(self.launched, end)
+
+    def _launch(self, a: int, b: int):
+        if b <= a:
+            return
+        chunk = self.flat[a:b]
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                self.handles.append(dist.all_reduce(chunk, group=self.pg, async_op=True))
+        else:
+            self.handles.append(dist.all_reduce(chunk, group=self.pg, async_op=True))
+        self.launched = b
+
+    def finish(self, scalars: Optional[torch.Tensor] = None, sample_size_index: int = 1):
+        """End of backward: reduce what is left, wait, scale by 1 / global sample size.
+        ``scalars`` (fp32 vector: loss, sample_size, counters...) is summed over ranks in place."""
+        if self.world > 1:
+            self._launch(self.launched, self.flat.numel())
+            if scalars is not None:
+                self.handles.append(dist.all_reduce(scalars, group=self.pg, async_op=True) if self.comm_stream is None
+                                    else self._scalar_reduce(scalars))
+            for h in self.handles:
+                h.wait()
+            if self.comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if scalars is not None:
+            self.flat.div_(scalars[sample_size_index].clamp(min=1.0))
+        self.reset()
+
+    def _scalar_reduce(self, scalars):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.comm_stream.wait_event(ev)
+        with torch.cuda.stream(self.comm_stream):
+            return dist.all_reduce(scalars, group=self.pg, async_op=True)
+
+
+class DataParallel:
+    """Wrap a ``GraphormerModel`` for one-process-per-GPU data parallelism."""
+
+    def __init__(self, model, bucket_mb: int = 64, process_group=None):
+        self.model = model
+        flat = model.prepare_main_grads()
+        ge = model.encoder.graph_encoder
+        params = [p for p in model.parameters() if p.requires_grad and hasattr(p, "main_grad")]
+        stream = torch.cuda.Stream() if flat.is_cuda else None
+        self.bucketer = GradientBucketer(params, flat, bucket_mb << 20, process_group, stream)
+        ge.grad_ready_hook = self.bucketer.on_params_ready
+        self._steps = 0
+
+    def zero_grad(self):
+        self.model.main_grad_flat.zero_()
+
+    def finish_backward(self, logging_scalars: Optional[torch.Tensor] = None):
+        self.bucketer.finish(logging_scalars)
+        self._steps += 1
+        if not self.bucketer.layout_final:
+            self.bucketer.finalize_layout()       # after the first backward: completion-ordered buckets
+
+    def broadcast_parameters(self, src: int = 0):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            for p in self.model.parameters():
+                dist.broadcast(p.data, src)

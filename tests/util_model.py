@@ -80,12 +80,16 @@ def split_qkv_grad(name: str, grads: dict):
                 base = name.replace(pat, pat.replace(f".{part}.", ".qkv_"))
                 base = base.replace("qkv_weight", "qkv_weight").replace("qkv_bias", "qkv_bias")
                 g = grads[base]
+                if g is None:
+                    return None
                 d = g.shape[0] // 3
                 return g[i * d:(i + 1) * d]
     for i, part in enumerate(("q_proj", "k_proj", "v_proj")):
         pat = f".self_attn.{part}."
         if pat in name:
             g = grads[name.replace(pat, ".self_attn.qkv_")]
+            if g is None:
+                return None
             d = g.shape[0] // 3
             return g[i * d:(i + 1) * d]
     return grads.get(name)
