@@ -61,6 +61,16 @@ def flops_per_comment(L=100, nb=4, P=197, D=768, F=3072, Lb=6, Lf=6, G=6, N=64, 
     return text + rho * image + graph_tree / N + head
 
 
+def host_cores() -> int:
+    """CPU share of this process (the GPU box gives 16 cores per GPU; os.cpu_count() reports the
+    whole host and oversubscribing it makes torch-CPU crawl)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 class GemmTimer:
     """HIP-event timing of every mdt_gemm launch on the current stream (tile kernel only)."""
 
@@ -106,7 +116,7 @@ def cpu_baseline(args):
     from multimodaldiscussiontransformer_amd import synthetic
     from oracle import mdt_ref_cpu as R
     from oracle import structure as S
-    ncores = os.cpu_count() or 1
+    ncores = host_cores()
     torch.set_num_threads(ncores)
     hp = R.hparams(dim=768, enc_heads=12, graph_heads=12, enc_ffn=3072, graph_ffn=768, text_layers=12, vit_layers=12,
                    num_fusion_layers=args.num_fusion_layers, num_fusion_stack=1, num_graph_stack=1, num_bottleneck=4,
@@ -151,6 +161,7 @@ def main():
     args = ap.parse_args()
 
     import torch.distributed as dist
+    torch.set_num_threads(host_cores())
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

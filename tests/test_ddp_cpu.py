@@ -1,0 +1,103 @@
+"""world_size-2 gloo test of the data-parallel gradient exchange (the same GradientBucketer the
+GPU path drives with RCCL): bucketed in-place all-reduce of the flat fp32 arena in completion
+order, completion-order re-layout after the first step, parameters that never report, and the
+FairSeq-convention scaling by the global sample size."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multimodaldiscussiontransformer_amd.ddp import GradientBucketer
+        torch.manual_seed(0)
+        shapes = [(64, 8), (8,), (128, 16), (16,), (32, 32), (5,), (300,)]
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+        params[5].requires_grad = False                       # frozen: never enters the arena
+        train = [p for p in params if p.requires_grad]
+        flat = torch.zeros(sum(p.numel() for p in train))
+        b = GradientBucketer(params, flat, bucket_bytes=4 * 600)      # small buckets → several all-reduces
+        fire_order = [[train[4], train[2]], [train[3]], [train[0], train[1]]]   # train[5] (the [300] vector) never reports
+        results = []
+        for step in range(3):
+            flat.zero_()
+            g = torch.Generator().manual_seed(100 * step + rank)
+            local = {}
+            for p in train:
+                v = torch.randn(p.shape, generator=g)
+                p.main_grad.copy_(v)
+                local[id(p)] = v
+            for grp in fire_order:
+                b.on_params_ready(grp)
+            scal = torch.tensor([1.5 + rank, float(2 + rank), 1.0, 0.0, 1.0, 1.0])
+            b.finish(scal)
+            if not b.layout_final:
+                b.finalize_layout()
+            # expected: sum over ranks / global sample size
+            tot = float(sum(2 + r for r in range(world)))
+            for p in train:
+                exp = torch.zeros(p.shape)
+                for r in range(world):
+                    gr = torch.Generator().manual_seed(100 * step + r)
+                    for q2 in train:
+                        v = torch.randn(q2.shape, generator=gr)
+                        if q2 is p:
+                            exp += v
+                torch.testing.assert_close(p.main_grad, exp / tot, atol=1e-6, rtol=1e-6)
+            assert abs(float(scal[1]) - tot) < 1e-6 and abs(float(scal[0]) - sum(1.5 + r for r in range(world))) < 1e-6
+            results.append(True)
+        # after re-layout the arena starts with the first-finished group and ends with the silent parameter
+        first = b.slots[0][0]
+        assert first == id(train[4]) and b.slots[-1][0] == id(train[5])
+        q.put((rank, "ok", len(results)))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_bucketer_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info in out:
+        assert status == "ok", f"rank {rank}: {info}"
+
+
+def test_relayout_preserves_gradients_single_process():
+    from multimodaldiscussiontransformer_amd.ddp import GradientBucketer
+    params = [torch.nn.Parameter(torch.zeros(4, 3)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2, 2))]
+    flat = torch.zeros(12 + 5 + 4)
+    b = GradientBucketer(params, flat)
+    for i, p in enumerate(params):
+        p.main_grad.fill_(float(i + 1))
+    b.on_params_ready([params[2]])
+    b.on_params_ready([params[0]])
+    b.finish(None)
+    b.finalize_layout()
+    assert [s[0] for s in b.slots] == [id(params[2]), id(params[0]), id(params[1])]
+    for i, p in enumerate(params):
+        assert torch.all(p.main_grad == float(i + 1))
+        assert p.main_grad.data_ptr() >= flat.data_ptr()
