@@ -12,6 +12,8 @@
 //    fp32 FMA chains) — the fp32 parity path and the fallback for odd shapes.
 //
 // Replaces the nn.Linear calls of the reference (see include/mdt_hip.h, mdt_gemm).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mdt {
@@ -124,24 +126,26 @@ constexpr int T_TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand per stage
 __device__ __forceinline__ int swz_kc(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int swz_km(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
-// Issue the LDS-DMA loads of one operand tile (16 KiB = 16 pieces of 1 KiB; wave w
-// issues pieces w, w+4, w+8, w+12).  `rs` covers the operand from its first tile row.
-template <bool KM>
+// Issue the LDS-DMA loads of one operand tile of ROWS rows|columns x 64 k (ROWS = 128 or 256):
+// ROWS/8 pieces of 1 KiB, dealt round-robin to the NW waves of the block.
+//   k-contiguous: piece = 8 rows x 128 B;  k-major: piece = (1024 / (2*ROWS)) k-rows x 2*ROWS B.
+template <bool KM, int ROWS, int NW>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, int64_t ld_bytes, int64_t k0, int col0,
                                            char* lds_tile, int wave, int lane) {
+  constexpr int NPIECE = ROWS / 8;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int piece = wave + i * 4;
+  for (int i = 0; i < NPIECE / NW; ++i) {
+    const int piece = wave + i * NW;
     unsigned voff;
     if constexpr (!KM) {
-      // piece = 8 rows x 128 B; lane -> row piece*8 + lane/8, LDS chunk' = lane%8
       const int row = piece * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ swz_kc(row);
       voff = (unsigned)(row * ld_bytes + (k0 + chunk * 8) * 2);
     } else {
-      // piece = 4 k-rows x 256 B; lane -> k piece*4 + lane/16, LDS 16-B chunk' = lane%16
-      const int k = piece * 4 + (lane >> 4);
-      const int c16 = lane & 15;
+      constexpr int C16 = ROWS / 8;        // 16-B chunks per k-row
+      constexpr int KPP = 64 / C16;        // k-rows per piece
+      const int k = piece * KPP + lane / C16;
+      const int c16 = lane % C16;
       const int blk = (c16 >> 1) ^ swz_km(k);
       voff = (unsigned)((k0 + k) * ld_bytes + (col0 + blk * 16 + (c16 & 1) * 8) * 2);
     }
@@ -150,20 +154,113 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, int64_t ld
 }
 
 // Fragment of a 16(row|col) x 32(k) block for k-step ks (0/1) of the staged tile.
-template <bool KM>
+template <bool KM, int ROWS>
 __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int rc_base, int ks, int lane) {
   if constexpr (!KM) {
     const int row = rc_base + (lane & 15);
     const int chunk = (ks * 4 + (lane >> 4)) ^ swz_kc(row);
     return *(const bf16x8*)(lds_tile + row * 128 + chunk * 16);
   } else {
+    constexpr int RB = ROWS * 2;           // bytes per k-row
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     const int blk = rc_base >> 4;
     const int k_lo = ks * 32 + g * 8 + q;
     const int k_hi = k_lo + 4;
-    const bf16x4 lo = lds_read_tr16((const bf16_t*)(lds_tile + k_lo * 256 + ((blk ^ swz_km(k_lo)) * 32) + pp * 8));
-    const bf16x4 hi = lds_read_tr16((const bf16_t*)(lds_tile + k_hi * 256 + ((blk ^ swz_km(k_hi)) * 32) + pp * 8));
+    const bf16x4 lo = lds_read_tr16((const bf16_t*)(lds_tile + k_lo * RB + ((blk ^ swz_km(k_lo)) * 32) + pp * 8));
+    const bf16x4 hi = lds_read_tr16((const bf16_t*)(lds_tile + k_hi * RB + ((blk ^ swz_km(k_hi)) * 32) + pp * 8));
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+}
+
+// Epilogue of the tile kernel: each wave parks its 64x64 fp32 accumulator block in LDS
+// (the staging buffers are free once the K loop is done), then walks it row-wise so that
+// every global access is a full 16-byte vector and a wave instruction covers whole 128-B
+// (bf16) row segments — bias / GELU / residual / pre-activation traffic is coalesced too.
+// Split-K weight gradients leave with one 256-byte contiguous atomic instruction per row.
+template <typename TOut>
+__device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], char* smem, int wave, int lane,
+                                              int64_t m0w, int64_t n0w) {
+  __syncthreads();  // every wave is done reading the last staged tile
+  float* ws = (float*)(smem + wave * 16384);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ws[(i * 16 + (lane >> 4) * 4 + r) * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int ep = p.epilogue;
+  if constexpr (sizeof(TOut) == 4) {
+    if (ep & MDT_EPI_ATOMIC) {
+      float* c = (float*)p.C + n0w + lane;
+      for (int row = 0; row < 64; ++row) {
+        const int64_t gr = m0w + row;
+        if (gr < p.M) atomicAdd(c + gr * p.ldc, p.alpha * ws[row * 64 + lane]);
+      }
+      return;
+    }
+  }
+  const int c8 = (lane & 7) * 8;
+  const int64_t gc = n0w + c8;
+  float bias[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+  if (ep & MDT_EPI_BIAS) {
+    const bf16x8 b = *(const bf16x8*)((const bf16_t*)p.bias + gc);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = (float)b[e];
+  }
+#pragma unroll 2
+  for (int pass = 0; pass < 8; ++pass) {
+    const int row = pass * 8 + (lane >> 3);
+    const int64_t gr = m0w + row;
+    if (gr >= p.M) continue;
+    const f32x4 lo = *(const f32x4*)(ws + row * 64 + c8);
+    const f32x4 hi = *(const f32x4*)(ws + row * 64 + c8 + 4);
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
+    if (ep & MDT_EPI_GELU) {
+      if (p.aux) {
+        bf16x8 u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { u[e] = (bf16_t)v[e]; v[e] = (float)u[e]; }  // backward differentiates at the stored value
+        *(bf16x8*)((bf16_t*)p.aux + gr * p.ldaux + gc) = u;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+    }
+    if (ep & MDT_EPI_DGELU) {
+      const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + gr * p.ldaux + gc);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad((float)u[e]);
+    }
+    if (ep & MDT_EPI_RESIDUAL) {
+      const bf16x8 r = *(const bf16x8*)((const bf16_t*)p.residual + gr * p.ldr + gc);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+    }
+    if constexpr (sizeof(TOut) == 4) {
+      float* c = (float*)p.C + gr * p.ldc + gc;
+      if (ep & MDT_EPI_ACCUM) {
+        const f32x4 o0 = *(const f32x4*)c, o1 = *(const f32x4*)(c + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += o0[e]; v[4 + e] += o1[e]; }
+      }
+      *(f32x4*)c = f32x4{v[0], v[1], v[2], v[3]};
+      *(f32x4*)(c + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+      bf16_t* c = (bf16_t*)p.C + gr * p.ldc + gc;
+      if (ep & MDT_EPI_ACCUM) {
+        const bf16x8 o = *(const bf16x8*)c;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)o[e];
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+      *(bf16x8*)c = o;
+    }
   }
 }
 
@@ -212,8 +309,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile128(GemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (nk > 0) {
-    stage_tile<A_KM>(rsA, lda_b, a_k0, a_col0, smem, wave, lane);
-    stage_tile<B_KM>(rsB, ldb_b, b_k0, b_col0, smem + T_TILE_BYTES, wave, lane);
+    stage_tile<A_KM, 128, 4>(rsA, lda_b, a_k0, a_col0, smem, wave, lane);
+    stage_tile<B_KM, 128, 4>(rsB, ldb_b, b_k0, b_col0, smem + T_TILE_BYTES, wave, lane);
   }
   for (int kt = 0; kt < nk; ++kt) {
     char* cur = smem + (kt & 1) * 2 * T_TILE_BYTES;
@@ -222,30 +319,119 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile128(GemmParams p) {
     // + everyone finished reading the buffer tile kt+1 is about to overwrite
     __syncthreads();
     if (kt + 1 < nk) {
-      stage_tile<A_KM>(rsA, lda_b, a_k0 + (int64_t)(kt + 1) * T_BK, a_col0, nxt, wave, lane);
-      stage_tile<B_KM>(rsB, ldb_b, b_k0 + (int64_t)(kt + 1) * T_BK, b_col0, nxt + T_TILE_BYTES, wave, lane);
+      stage_tile<A_KM, 128, 4>(rsA, lda_b, a_k0 + (int64_t)(kt + 1) * T_BK, a_col0, nxt, wave, lane);
+      stage_tile<B_KM, 128, 4>(rsB, ldb_b, b_k0 + (int64_t)(kt + 1) * T_BK, b_col0, nxt + T_TILE_BYTES, wave, lane);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 a[4], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = load_frag<A_KM>(cur, wr * 64 + i * 16, ks, lane);
+      for (int i = 0; i < 4; ++i) a[i] = load_frag<A_KM, 128>(cur, wr * 64 + i * 16, ks, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = load_frag<B_KM>(cur + T_TILE_BYTES, wc * 64 + j * 16, ks, lane);
+      for (int j = 0; j < 4; ++j) b[j] = load_frag<B_KM, 128>(cur + T_TILE_BYTES, wc * 64 + j * 16, ks, lane);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(a[i], b[j], acc[i][j]);
     }
   }
+  tile_epilogue<TOut>(p, acc, smem, wave, lane, m0 + wr * 64, n0 + wc * 64);
+}
+
+// ------------------------------------------------------------------ bf16 256-row tiles, 8 waves
+// One block (512 threads = 8 waves, two per SIMD) per CU.
+//   <BN=128, 4x2 waves, 3 stages>: 64x64 per wave; the LDS-DMA loads of K-step kt+2 are issued
+//       while kt computes, each wave waits with a COUNTED vmcnt (its newest loads — step kt+1 —
+//       stay in flight) and the block meets at a raw s_barrier, so loads never drain to zero in
+//       the loop (cdna_hip_programming.md "Pipelining across barriers").
+//   <BN=256, 2x4 waves, 2 stages>: 128x64 per wave — 131 flops per byte pulled from L2 into LDS
+//       (128x128 tiles: 65) and 0.375 ds_read_b128 per MFMA (0.5): the variant for the big
+//       token-count GEMMs, whose limiter is the L2 -> LDS stream, not HBM.
+template <typename TOut, bool A_KM, bool B_KM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(512) void gemm_bf16_tile256(GemmParams p) {
+  constexpr int BM = 256;
+  constexpr int MI = BM / WM / 16, NI = BN / WN / 16;          // 16x16 accumulator tiles per wave
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int LOADS = (BM + BN) / 64;                          // LDS-DMA instructions per wave per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * p.k_chunk;
+  const int64_t kend = (kbeg + p.k_chunk < p.K) ? kbeg + p.k_chunk : p.K;
+  const int nk = (int)((kend - kbeg + T_BK - 1) / T_BK);
+
+  const int64_t lda_b = p.lda * 2, ldb_b = p.ldb * 2;
+  const char* a_base;
+  const char* b_base;
+  int64_t a_bytes, b_bytes;
+  if constexpr (!A_KM) { a_base = (const char*)p.A + m0 * lda_b; a_bytes = (p.M - m0) * lda_b; }
+  else { a_base = (const char*)p.A + kbeg * lda_b; a_bytes = (kend - kbeg) * lda_b; }
+  if constexpr (!B_KM) { b_base = (const char*)p.B + n0 * ldb_b; b_bytes = (p.N - n0) * ldb_b; }
+  else { b_base = (const char*)p.B + kbeg * ldb_b; b_bytes = (kend - kbeg) * ldb_b; }
+  const unsigned a_rec = (unsigned)(a_bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : a_bytes);
+  const unsigned b_rec = (unsigned)(b_bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : b_bytes);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, a_rec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, b_rec, 0x00020000);
+  const int64_t a_k0 = A_KM ? 0 : kbeg, b_k0 = B_KM ? 0 : kbeg;
+  const int a_col0 = A_KM ? (int)m0 : 0, b_col0 = B_KM ? (int)n0 : 0;
+
+  f32x4 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int kt) {
+    char* st = smem + (kt % NSTAGE) * STAGE;
+    stage_tile<A_KM, BM, 8>(rsA, lda_b, a_k0 + (int64_t)kt * T_BK, a_col0, st, wave, lane);
+    stage_tile<B_KM, BN, 8>(rsB, ldb_b, b_k0 + (int64_t)kt * T_BK, b_col0, st + A_BYTES, wave, lane);
+  };
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        epilogue_store<bf16_t, TOut>(p, m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r,
-                                     n0 + wc * 64 + j * 16 + (lane & 15), acc[i][j][r]);
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (nk > s) issue(s);
+  for (int kt = 0; kt < nk; ++kt) {
+    // this wave's loads of step kt have landed once only the loads of later steps are pending
+    if (NSTAGE == 3 && kt + 1 < nk) {
+      if constexpr (LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();   // every wave's part of step kt is in LDS; step kt-1 is fully consumed
+    if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1);   // overwrites the stage step kt-1 used
+    const char* cur = smem + (kt % NSTAGE) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[MI], b[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = load_frag<B_KM, BN>(cur + A_BYTES, wc * (NI * 16) + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = load_frag<A_KM, BM>(cur, wr * (MI * 16) + i * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16(a[i], b[j], acc[i][j]);
+    }
+  }
+  // 64x64 blocks through the wave's 16 KiB LDS slot, one (MI = 4) or two (MI = 8) of them
+#pragma unroll
+  for (int h = 0; h < MI / 4; ++h) {
+    f32x4 blk[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) blk[i][j] = acc[h * 4 + i][j];
+    tile_epilogue<TOut>(p, blk, smem, wave, lane, m0 + wr * (MI * 16) + h * 64, n0 + wc * 64);
+  }
 }
 
 // ------------------------------------------------------------------ helpers
@@ -267,6 +453,36 @@ __global__ __launch_bounds__(BLOCK) void colsum_kernel(int64_t M, int64_t N, con
   red[rl][threadIdx.x & 63] = s;
   __syncthreads();
   if (rl == 0 && c < N) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// 16-byte-vectorised column sum: lane = VN consecutive columns, the 4 waves of a block interleave rows
+template <typename TIn, int VN>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(int64_t M, int64_t N, const TIn* X, int64_t ldx, float* out,
+                                                         int rows_per_block, const int32_t* row_weight) {
+  typedef __attribute__((ext_vector_type(VN))) TIn vec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t c = ((int64_t)blockIdx.x * 64 + lane) * VN;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
+  float acc[VN];
+#pragma unroll
+  for (int e = 0; e < VN; ++e) acc[e] = 0.f;
+  if (c < N) {
+    for (int64_t r = r0 + wave; r < r1; r += 4) {
+      const vec v = *(const vec*)(X + r * ldx + c);
+      const float w = row_weight ? (float)row_weight[r] : 1.f;
+#pragma unroll
+      for (int e = 0; e < VN; ++e) acc[e] += w * to_f32((TIn)v[e]);
+    }
+  }
+  __shared__ float red[4][64 * VN];
+#pragma unroll
+  for (int e = 0; e < VN; ++e) red[wave][lane * VN + e] = acc[e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * VN; i += 256) {
+    const int64_t col = (int64_t)blockIdx.x * 64 * VN + i;
+    if (col < N) atomicAdd(out + col, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+  }
 }
 
 template <typename TS, typename TD>
@@ -309,6 +525,32 @@ static int launch_tile128(hipStream_t st, const GemmParams& p, int ta, int tb) {
   return check_launch("gemm_bf16_tile128");
 }
 
+template <typename TOut, int BN, int WM, int WN, int NSTAGE>
+static int launch_tile256(hipStream_t st, const GemmParams& p, int ta, int tb) {
+  dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)p.split_k);
+  const size_t lds = (size_t)NSTAGE * (256 + BN) * 128;
+#define L256(A_, B_)                                                                                         \
+  {                                                                                                          \
+    auto kern = gemm_bf16_tile256<TOut, A_, B_, BN, WM, WN, NSTAGE>;                                         \
+    static bool attr_set = false;                                                                            \
+    if (!attr_set) {                                                                                         \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+        (void)hipGetLastError();                                                                             \
+        set_error("gemm_bf16_tile256: cannot reserve %zu bytes of LDS", lds);                                \
+        return MDT_ERR_LAUNCH;                                                                               \
+      }                                                                                                      \
+      attr_set = true;                                                                                       \
+    }                                                                                                        \
+    hipLaunchKernelGGL(kern, grid, 512, lds, st, p);                                                         \
+  }
+  if (!ta && !tb) L256(false, false)
+  else if (!ta && tb) L256(false, true)
+  else if (ta && !tb) L256(true, false)
+  else L256(true, true)
+#undef L256
+  return check_launch("gemm_bf16_tile256");
+}
+
 }  // namespace mdt
 
 using namespace mdt;
@@ -346,6 +588,12 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
     // 32-bit buffer offsets: one 128-row panel (k-contiguous) or one k-chunk (k-major) must stay < 4 GiB
     fast = a_ok && b_ok && al && (N % T_BN == 0 || !trans_b) && lda * 2 * 128 < (1ll << 31) && ldb * 2 * 128 < (1ll << 31);
     if (!trans_b && N % T_BN != 0) fast = false;  // B rows beyond N would alias the next tensor
+    // vector epilogue: 16-byte accesses on C / bias / residual / aux
+    const int ov = out_dtype == MDT_F32 ? 4 : 8;
+    if (ldc % ov || ((uintptr_t)C & 15)) fast = false;
+    if ((epilogue & MDT_EPI_BIAS) && ((uintptr_t)bias & 15)) fast = false;
+    if ((epilogue & MDT_EPI_RESIDUAL) && (ldr % 8 || ((uintptr_t)residual & 15))) fast = false;
+    if (aux && (ldaux % 8 || ((uintptr_t)aux & 15))) fast = false;
   }
   if (fast) {
     int64_t chunk = ((K + split_k - 1) / split_k + T_BK - 1) / T_BK * T_BK;
@@ -356,6 +604,30 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
     if ((trans_a || trans_b) && chunk * (trans_a ? lda : ldb) * 2 >= (1ll << 32)) fast = false;
   }
   if (fast) {
+    // big problems: 256-row tiles, one 8-wave block per CU; small ones keep 128x128 (2 blocks / CU)
+    const char* force = getenv("MDT_GEMM_TILE");      // "128" | "256x128" | "256x256" (tuning / A-B runs)
+    const bool m256 = trans_a ? (M % 256 == 0) : true;
+    const int64_t t256 = ((M + 255) / 256) * (N / 128) * p.split_k;
+    const bool n256 = N % 256 == 0;
+    // 256x256 whenever it still fills most of the chip (1 block per CU): its L2 -> LDS traffic per
+    // flop is half that of 128x128 and measured 10-40 % faster at every C2 shape (profiles/)
+    bool use256x256 = m256 && n256 && t256 / 2 >= 200;
+    bool use256x128 = m256 && !use256x256 && t256 >= 256;
+    if (force) {
+      use256x256 = m256 && n256 && !strcmp(force, "256x256");
+      use256x128 = m256 && !strcmp(force, "256x128");
+    }
+    if (use256x256) {
+      p.tiles_m = (int)((M + 255) / 256);
+      p.tiles_n = (int)(N / 256);
+      return out_dtype == MDT_F32 ? launch_tile256<float, 256, 2, 4, 2>(st, p, trans_a, trans_b)
+                                  : launch_tile256<bf16_t, 256, 2, 4, 2>(st, p, trans_a, trans_b);
+    }
+    if (use256x128) {
+      p.tiles_m = (int)((M + 255) / 256);
+      return out_dtype == MDT_F32 ? launch_tile256<float, 128, 4, 2, 3>(st, p, trans_a, trans_b)
+                                  : launch_tile256<bf16_t, 128, 4, 2, 3>(st, p, trans_a, trans_b);
+    }
     return out_dtype == MDT_F32 ? launch_tile128<float>(st, p, trans_a, trans_b)
                                 : launch_tile128<bf16_t>(st, p, trans_a, trans_b);
   }
@@ -371,13 +643,25 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
 extern "C" int mdt_colsum(void* stream, int dtype, int64_t M, int64_t N, const void* X, int64_t ldx, float* out,
                           const int32_t* row_weight) {
   MDT_CHECK_ARG(X && out, "mdt_colsum: null pointer");
+  MDT_CHECK_ARG(dtype == MDT_F32 || dtype == MDT_BF16, "mdt_colsum: dtype %d", dtype);
   if (M == 0 || N == 0) return MDT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int vn = dtype == MDT_BF16 ? 8 : 4;
+  if (N % vn == 0 && ldx % vn == 0 && ((uintptr_t)X & 15) == 0) {
+    const unsigned gx = (unsigned)((N + 64 * vn - 1) / (64 * vn));
+    int64_t chunks = 2048 / gx;
+    if (chunks < 1) chunks = 1;
+    int rows_per_block = (int)((M + chunks - 1) / chunks);
+    if (rows_per_block < 32) rows_per_block = 32;
+    dim3 grid(gx, (unsigned)((M + rows_per_block - 1) / rows_per_block));
+    if (dtype == MDT_F32) hipLaunchKernelGGL((colsum_vec_kernel<float, 4>), grid, 256, 0, st, M, N, (const float*)X, ldx, out, rows_per_block, row_weight);
+    else hipLaunchKernelGGL((colsum_vec_kernel<bf16_t, 8>), grid, 256, 0, st, M, N, (const bf16_t*)X, ldx, out, rows_per_block, row_weight);
+    return check_launch("colsum_vec");
+  }
   const int rows_per_block = 512;
   dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rows_per_block - 1) / rows_per_block));
-  hipStream_t st = (hipStream_t)stream;
   if (dtype == MDT_F32) hipLaunchKernelGGL((colsum_kernel<float, 256>), grid, 256, 0, st, M, N, (const float*)X, ldx, out, rows_per_block, row_weight);
-  else if (dtype == MDT_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t, 256>), grid, 256, 0, st, M, N, (const bf16_t*)X, ldx, out, rows_per_block, row_weight);
-  else MDT_UNSUPPORTED("mdt_colsum: dtype %d", dtype);
+  else hipLaunchKernelGGL((colsum_kernel<bf16_t, 256>), grid, 256, 0, st, M, N, (const bf16_t*)X, ldx, out, rows_per_block, row_weight);
   return check_launch("colsum");
 }
 

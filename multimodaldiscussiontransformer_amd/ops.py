@@ -112,7 +112,7 @@ def attention_fwd(qkv, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None,
     """qkv [rows, 3*D] → (out [rows, D], lse f32[nseq, H, S])."""
     D = qkv.shape[1] // 3
     hd = D // H
-    out = torch.zeros(qkv.shape[0], D, dtype=qkv.dtype, device=qkv.device)
+    out = torch.empty(qkv.shape[0], D, dtype=qkv.dtype, device=qkv.device)   # every row belongs to a sequence
     lse = torch.empty(nseq, H, S, dtype=torch.float32, device=qkv.device)
     a = _attn_args(qkv, out, lse, nseq, S, H, hd, S if seq_stride is None else seq_stride, pos_stride,
                    hd ** -0.5 if scale is None else scale, key_mask, dense_bias, attn_bias, spatial_pos, sp_table,
@@ -126,7 +126,7 @@ def attention_bwd(dout, qkv, out, lse, nseq, S, H, *, seq_stride=None, pos_strid
                   want_dense_dbias=False, d_sp_table=None, d_virt=None):
     D = qkv.shape[1] // 3
     hd = D // H
-    dqkv = torch.zeros_like(qkv)
+    dqkv = torch.empty_like(qkv)
     b = L.AttnBwdArgs()
     b.f = _attn_args(qkv, out, lse, nseq, S, H, hd, S if seq_stride is None else seq_stride, pos_stride,
                      hd ** -0.5 if scale is None else scale, key_mask, dense_bias, attn_bias, spatial_pos, sp_table,

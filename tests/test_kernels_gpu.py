@@ -105,6 +105,50 @@ def test_gemm_bf16_wgrad_splitk_and_epilogues(ops):
     torch.testing.assert_close(out.float().cpu(), u + res.float(), atol=0.03, rtol=1e-2)
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_bf16_tile256_pipeline(ops, ta, tb):
+    """Shapes large enough for the 256x128 three-stage kernel (>= 256 tiles), ragged M tail,
+    K from 1 to many pipeline steps, every operand layout."""
+    for (M, N, K) in [(33000, 256, 64), (33000, 256, 192), (16640, 512, 1024), (66000, 512, 192), (131072 + 77, 256, 64)]:
+        if ta:
+            M = (M // 256) * 256
+        a = (rnd(K, M, seed=1) if ta else rnd(M, K, seed=1)).bfloat16()
+        b = (rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)).bfloat16()
+        ad, bd = dev(a), dev(b)
+        ref = ((ad.float().t() if ta else ad.float()) @ (bd.float() if tb else bd.float().t())).cpu()
+        out32 = ops.gemm(ad, bd, trans_a=bool(ta), trans_b=bool(tb), out_dtype=torch.float32)
+        torch.testing.assert_close(out32.cpu(), ref, atol=2e-3, rtol=1e-3)
+    # epilogues through the pipeline kernel
+    if not ta and not tb:
+        M, N, K = 33000, 256, 128
+        a, b = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, scale=0.2).bfloat16()
+        bias, res = rnd(N, seed=3).bfloat16(), rnd(M, N, seed=4).bfloat16()
+        u = a.float() @ b.float().t() + bias.float()
+        aux = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+        out = ops.gemm(dev(a), dev(b), bias=dev(bias), aux=aux, epilogue=ops.EPI_GELU)
+        torch.testing.assert_close(aux.float().cpu(), u, atol=0.03, rtol=1e-2)
+        torch.testing.assert_close(out.float().cpu(), F.gelu(u), atol=0.03, rtol=1e-2)
+        out = ops.gemm(dev(a), dev(b), bias=dev(bias), residual=dev(res))
+        torch.testing.assert_close(out.float().cpu(), u + res.float(), atol=0.03, rtol=1e-2)
+        x = u.clone().requires_grad_(True)
+        F.gelu(x).backward(a.float() @ b.float().t())
+        out = ops.gemm(dev(a), dev(b), aux=dev(u.bfloat16()), epilogue=ops.EPI_DGELU, out_dtype=torch.float32)
+        xb = u.bfloat16().float().requires_grad_(True)
+        F.gelu(xb).backward(a.float() @ b.float().t())
+        torch.testing.assert_close(out.cpu(), xb.grad, atol=2e-3, rtol=1e-3)
+    if ta and tb:   # split-K weight gradient with a ragged reduction tail
+        Mred, N, K = 50000, 1024, 1024
+        dy, x = rnd(Mred, N, seed=5, scale=0.1).bfloat16(), rnd(Mred, K, seed=6, scale=0.1).bfloat16()
+        dyd, xd = dev(dy), dev(x)
+        ref = (dyd.float().t() @ xd.float()).cpu()
+        c = torch.zeros(N, K, dtype=torch.float32).cuda()
+        ops.gemm(dyd, xd, trans_a=True, trans_b=True, out=c, epilogue=ops.EPI_ATOMIC, split_k=8)
+        torch.testing.assert_close(c.cpu(), ref, atol=5e-3, rtol=2e-3)
+        c.zero_()                                   # 16 slices -> the 256x256 tile variant
+        ops.gemm(dyd, xd, trans_a=True, trans_b=True, out=c, epilogue=ops.EPI_ATOMIC, split_k=16)
+        torch.testing.assert_close(c.cpu(), ref, atol=5e-3, rtol=2e-3)
+
+
 def test_colsum_cast_transpose(ops):
     x = rnd(1037, 200, seed=9)
     torch.testing.assert_close(ops.colsum(dev(x)).cpu(), x.sum(0), atol=1e-3, rtol=1e-5)

@@ -25,7 +25,18 @@ def main():
     dev = "cuda"
     bf = torch.bfloat16
     M = 212992
-    print("== GEMM bf16 (tile128) ==")
+    import os
+    for force in ("128", "256x128", "256x256", None):
+        if force is None:
+            os.environ.pop("MDT_GEMM_TILE", None)
+        else:
+            os.environ["MDT_GEMM_TILE"] = force
+        print(f"== GEMM bf16, tile = {force or 'auto'} ==")
+        gemm_section(M, dev, bf)
+    rest(M, dev, bf)
+
+
+def gemm_section(M, dev, bf):
     for (m, n, k, ta, tb, name) in [
         (M, 2304, 768, 0, 0, "qkv fwd"), (M, 768, 768, 0, 0, "out fwd"), (M, 3072, 768, 0, 0, "ffn1 fwd"),
         (M, 768, 3072, 0, 0, "ffn2 fwd"), (M, 768, 2304, 0, 1, "qkv dgrad"), (M, 768, 3072, 0, 1, "ffn1 dgrad"),
@@ -37,21 +48,26 @@ def main():
         t = timeit(lambda: ops.gemm(a, b, trans_b=bool(tb), out=out))
         print(f"{name:12s} M={m} N={n} K={k}: {t*1e3:8.3f} ms  {2*m*n*k/t/1e12:7.1f} TF/s")
         del a, b, out
-    for (n, k, name, sk) in [(2304, 768, "qkv wgrad", 4), (768, 768, "out wgrad", 14), (3072, 768, "ffn1 wgrad", 4),
-                             (768, 3072, "ffn2 wgrad", 4)]:
+    from multimodaldiscussiontransformer_amd.engine import _split_k
+    for (n, k, name) in [(2304, 768, "qkv wgrad"), (768, 768, "out wgrad"), (3072, 768, "ffn1 wgrad"),
+                         (768, 3072, "ffn2 wgrad")]:
+        sk = _split_k(n, k, M)
         dy = torch.randn(M, n, device=dev, dtype=bf)
         x = torch.randn(M, k, device=dev, dtype=bf)
         c = torch.zeros(n, k, device=dev, dtype=torch.float32)
         t = timeit(lambda: ops.gemm(dy, x, trans_a=True, trans_b=True, out=c, epilogue=ops.EPI_ATOMIC, split_k=sk))
         print(f"{name:12s} N={n} K={k} red={M} split{sk}: {t*1e3:8.3f} ms  {2*M*n*k/t/1e12:7.1f} TF/s")
         del dy, x, c
-    print("== epilogues (ffn1 fwd bias+gelu+aux; ffn2 fwd bias+residual) ==")
+    print("-- epilogues (ffn1 fwd bias+gelu+aux) --")
     a = torch.randn(M, 768, device=dev, dtype=bf); b = torch.randn(3072, 768, device=dev, dtype=bf)
     bias = torch.randn(3072, device=dev, dtype=bf); aux = torch.empty(M, 3072, device=dev, dtype=bf)
     out = torch.empty(M, 3072, device=dev, dtype=bf)
     t = timeit(lambda: ops.gemm(a, b, bias=bias, aux=aux, out=out, epilogue=ops.EPI_GELU))
     print(f"ffn1 gelu: {t*1e3:8.3f} ms {2*M*3072*768/t/1e12:7.1f} TF/s")
     del a, b, bias, aux, out
+
+
+def rest(M, dev, bf):
     print("== attention bf16 ==")
     for (nseq, S, name) in [(2048, 104, "bert"), (512, 201, "vit"), (32, 65, "graph")]:
         H, hd = 12, 64
