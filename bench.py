@@ -240,7 +240,7 @@ def main():
         gs = timer.summary()
         roofline = None
         if gs:
-            roofline = dict(bound="mfma", kernel="gemm_bf16_tile128", achieved=round(gs["tflops"], 1),
+            roofline = dict(bound="mfma", kernel="gemm_bf16_tile256 (bf16 MFMA tile GEMM family: 256x256 / 256x128 / 128x128)", achieved=round(gs["tflops"], 1),
                             peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(gs["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4),
                             traffic=None, launches=gs["launches"], avg_launch_us=round(gs["avg_us"], 1),
                             share_of_step=round(gs["total_ms"] * 1e-3 / dt, 3))

@@ -590,7 +590,7 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
     if (!trans_b && N % T_BN != 0) fast = false;  // B rows beyond N would alias the next tensor
     // vector epilogue: 16-byte accesses on C / bias / residual / aux
     const int ov = out_dtype == MDT_F32 ? 4 : 8;
-    if (ldc % ov || ((uintptr_t)C & 15)) fast = false;
+    if (!(epilogue & MDT_EPI_ATOMIC) && (ldc % ov || ((uintptr_t)C & 15))) fast = false;   // atomics are scalar
     if ((epilogue & MDT_EPI_BIAS) && ((uintptr_t)bias & 15)) fast = false;
     if ((epilogue & MDT_EPI_RESIDUAL) && (ldr % 8 || ((uintptr_t)residual & 15))) fast = false;
     if (aux && (ldaux % 8 || ((uintptr_t)aux & 15))) fast = false;

@@ -36,6 +36,7 @@ class GradientBucketer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.order_observed: List[int] = []       # ids in completion order (first backward)
         self.layout_final = False
+        self.aligned = flat.numel() == sum((p.numel() + 63) // 64 * 64 for p in self.params)
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._assign_views(self.params)
         self.reset()
@@ -47,9 +48,10 @@ class GradientBucketer:
         for p in ordered:
             n = p.numel()
             p.main_grad = self.flat[off:off + n].view(p.shape)
-            self.slots.append((id(p), off, n))
-            off += n
-        assert off == self.flat.numel()
+            span = (n + 63) // 64 * 64 if self.aligned else n       # 256-byte aligned slots
+            self.slots.append((id(p), off, span))
+            off += span
+        assert off == self.flat.numel(), (off, self.flat.numel())
         self._pos = {pid: i for i, (pid, _, _) in enumerate(self.slots)}
 
     def finalize_layout(self):
@@ -63,11 +65,11 @@ class GradientBucketer:
                 ordered.append(self.params[self._index[pid]])
         ordered += [p for p in self.params if id(p) not in seen]
         old = self.flat.clone()
-        old_slots = {pid: (off, n) for pid, off, n in self.slots}
+        old_slots = {pid: off for pid, off, _ in self.slots}
         self._assign_views(ordered)
         for p in ordered:
-            off, n = old_slots[id(p)]
-            p.main_grad.view(-1).copy_(old[off:off + n])
+            off = old_slots[id(p)]
+            p.main_grad.view(-1).copy_(old[off:off + p.numel()])
         self.layout_final = True
         self.reset()
 

@@ -22,6 +22,11 @@ from ..registry import register_model, register_model_architecture
 logger = logging.getLogger(__name__)
 
 
+def _slot(n: int) -> int:
+    """arena slot size: 256-byte aligned so every main_grad view is vector-addressable"""
+    return (n + 63) // 64 * 64
+
+
 def safe_hasattr(obj, k):
     return getattr(obj, k, None) is not None
 
@@ -90,12 +95,12 @@ class GraphormerModel(nn.Module):
         params = [p for p in self.encoder.graph_encoder.live_parameters() if p.requires_grad]
         extra = [p for p in self.parameters() if p.requires_grad and all(p is not q for q in params)]
         params = params + extra
-        total = sum(p.numel() for p in params)
+        total = sum(_slot(p.numel()) for p in params)
         flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
         off = 0
         for p in reversed(params):
             p.main_grad = flat[off:off + p.numel()].view(p.shape)
-            off += p.numel()
+            off += _slot(p.numel())
         self.main_grad_flat = flat
         self.encoder.graph_encoder.use_main_grad = True
         return flat
