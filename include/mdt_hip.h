@@ -42,7 +42,10 @@ enum {
   MDT_EPI_RESIDUAL = 4,  /* + residual[m, n] */
   MDT_EPI_DGELU = 8,     /* * gelu'(aux[m, n]) (backward of MDT_EPI_GELU) */
   MDT_EPI_ACCUM = 16,    /* C += result (plain read-modify-write, fp32 or T) */
-  MDT_EPI_ATOMIC = 32    /* C (fp32) += result with float atomics (split-K weight gradients) */
+  MDT_EPI_ATOMIC = 32,   /* C (fp32) += result with float atomics (split-K weight gradients) */
+  MDT_EPI_DROPOUT = 64   /* inverted dropout on the value after bias / GELU and before the residual add
+                            (with MDT_EPI_DGELU: on the incoming gradient, before the GELU' factor);
+                            element (m, n) of site `drop_seed` uses counter m*N + n */
 };
 
 int mdt_abi_version(void);
@@ -63,7 +66,16 @@ int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int trans_b,
              const void* A, int64_t lda, const void* B, int64_t ldb,
              void* C, int64_t ldc, int epilogue, float alpha,
              const void* bias, const void* residual, int64_t ldr,
-             void* aux, int64_t ldaux, int split_k);
+             void* aux, int64_t ldaux, int split_k, float drop_p, uint64_t drop_seed);
+
+/* Inverted dropout as a stand-alone op: y[m, n] = x[m, n] * keep(seed, m*D + n) / (1 - p).  The mask is
+ * a pure function of (seed, counter), so calling it on the gradient with the same seed is the backward
+ * (FairseqDropout / nn.Dropout in modules/graphormer_graph_encoder_layer.py:127,136,138,
+ * modules/multigraphormer_graph_encoder.py:403 and inside HF BertLayer / ViTLayer). */
+int mdt_dropout(void* stream, int dtype, int64_t rows, int D, const void* x, int64_t ldx, void* y, int64_t ldy,
+                float p, uint64_t seed);
+/* Test hook: mask[i] = 1 if counter i of site `seed` is kept. */
+int mdt_dropout_mask(void* stream, int64_t n, float p, uint64_t seed, uint8_t* mask);
 
 /* Column sums: out[n] (+)= sum_m w[m] * X[m,n]  (bias gradients; w = NULL means 1, otherwise an
  * int32 row weight — token-type embedding gradient).  out is fp32, accumulated with atomics —
@@ -116,6 +128,8 @@ typedef struct {
   const void* virt;
   const uint8_t* key_pad;
   int num_spatial;
+  float drop_p;              /* attention-probability dropout (0 = off); counter ((s*H + h)*S + q)*S + key */
+  uint64_t drop_seed;
 } mdt_attn_fwd_args;
 int mdt_attention_fwd(void* stream, const mdt_attn_fwd_args* a);
 

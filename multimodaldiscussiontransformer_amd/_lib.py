@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmdt_hip.so")
 
 MDT_F32, MDT_BF16 = 0, 1
-EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_ACCUM, EPI_ATOMIC = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_ACCUM, EPI_ATOMIC, EPI_DROPOUT = 1, 2, 4, 8, 16, 32, 64
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -27,6 +27,7 @@ class AttnFwdArgs(C.Structure):
         ("qkv", _vp), ("ld_qkv", _i64), ("out", _vp), ("ld_out", _i64), ("lse", _vp),
         ("key_mask", _vp), ("dense_bias", _vp), ("attn_bias", _vp), ("spatial_pos", _vp),
         ("sp_table", _vp), ("virt", _vp), ("key_pad", _vp), ("num_spatial", _i),
+        ("drop_p", _f), ("drop_seed", C.c_uint64),
     ]
 
 
@@ -41,7 +42,9 @@ _SIGS = {
     "mdt_abi_version": ([], _i),
     "mdt_last_error_string": ([], C.c_char_p),
     "mdt_gemm": ([_vp, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _f, _vp, _vp, _i64,
-                  _vp, _i64, _i], _i),
+                  _vp, _i64, _i, _f, C.c_uint64], _i),
+    "mdt_dropout": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _i64, _f, C.c_uint64], _i),
+    "mdt_dropout_mask": ([_vp, _i64, _f, C.c_uint64, _vp], _i),
     "mdt_colsum": ([_vp, _i, _i64, _i64, _vp, _i64, _vp, _vp], _i),
     "mdt_layernorm_fwd": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _vp, _f, _vp, _i64, _vp, _vp], _i),
     "mdt_layernorm_bwd": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp], _i),

@@ -23,6 +23,7 @@ namespace mdt {
 
 struct AttnParams {
   mdt_attn_fwd_args f;
+  DropCfg drop;
   const void* dout; int64_t ld_dout;
   void* dqkv; int64_t ld_dqkv;
   float* d_dense_bias; float* d_sp_table; float* d_virt;
@@ -230,11 +231,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
         a.lse[((int64_t)seq * a.H + h) * S + q] = (sum[r] > 0.f) ? mx[r] + __logf(sum[r]) : -INFINITY;
       sum[r] = (sum[r] > 0.f) ? 1.0f / sum[r] : 0.f;
     }
+    const bool dropping = a.drop_p > 0.f;
+    const DropCfg dc = P.drop;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        scratch[((lane >> 4) * 4 + r) * sld + t * 16 + (lane & 15)] = from_f32<T>(sc[t][r] * sum[r]);
+      for (int r = 0; r < 4; ++r) {
+        float pv = sc[t][r] * sum[r];
+        if (dropping) {
+          const int q = q0 + (lane >> 4) * 4 + r, key = t * 16 + (lane & 15);
+          pv *= drop_scale(dc, (((uint64_t)seq * a.H + h) * S + q) * S + key);
+        }
+        scratch[((lane >> 4) * 4 + r) * sld + t * 16 + (lane & 15)] = from_f32<T>(pv);
+      }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // O = P @ V
     f32x4 o[ND];
@@ -317,6 +326,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams P) {
   __syncthreads();
 
   BiasCtx bc{seq, h, S, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
+  const bool dropping = a.drop_p > 0.f;
+  const DropCfg dc = P.drop;
   const Src<T> gQ{qkv, tld, S};
   const Src<T> gDO{dout, dld, S};
   const int n_t = (S + 15) >> 4;
@@ -356,6 +367,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams P) {
           const float l = s_lse[q];
           const float p = (v == -INFINITY || l == -INFINITY || !qok) ? 0.f : __expf(v - l);
           sc[t][r] = p;
+          if (dropping) dp[t][r] *= drop_scale(dc, (((uint64_t)seq * a.H + h) * S + q) * S + key);   // dP = dD * M / (1-p)
           del[r] += p * dp[t][r];
         }
       }
@@ -465,8 +477,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams P) {
           float v = sc[t][r] * a.scale + kb[r];
           if ((a.dense_bias || STRUCT) && key < S) v += pair_bias<T, STRUCT>(bc, qc, key);
           const float p = (v == -INFINITY || l == -INFINITY || !qok) ? 0.f : __expf(v - l);
-          sc[t][r] = p;                       // P^T
-          dp[t][r] = p * (dp[t][r] - de);     // dS^T
+          float ds = dp[t][r];
+          float pd = p;
+          if (dropping) {
+            const float m = drop_scale(dc, (((uint64_t)seq * a.H + h) * S + qc) * S + key);
+            ds *= m;                          // dP^T = dD^T * M / (1-p)
+            pd *= m;                          // D^T  = P^T * M / (1-p)
+          }
+          sc[t][r] = pd;                      // (dropped) P^T, the operand of dV
+          dp[t][r] = p * (ds - de);           // dS^T
         }
       }
       // dV = P^T dO
@@ -615,9 +634,11 @@ extern "C" int mdt_attention_fwd(void* stream, const mdt_attn_fwd_args* a) {
   MDT_CHECK_ARG(a, "attention_fwd: null args");
   if (a->nseq == 0) return MDT_OK;
   if (int e = check_args(*a)) return e;
+  MDT_CHECK_ARG(a->drop_p >= 0.f && a->drop_p < 1.f, "attention_fwd: dropout p=%f out of [0,1)", a->drop_p);
   AttnParams p;
   memset(&p, 0, sizeof(p));
   p.f = *a;
+  p.drop = make_drop(a->drop_p, a->drop_seed);
   return dispatch<false>((hipStream_t)stream, p);
 }
 
@@ -631,6 +652,7 @@ extern "C" int mdt_attention_bwd(void* stream, const mdt_attn_bwd_args* a) {
     MDT_CHECK_ARG(a->ld_dout % 8 == 0 && ((uintptr_t)a->dout & 15) == 0, "attention_bwd(bf16): dout must be 16-byte aligned rows");
   AttnParams p;
   p.f = a->f;
+  p.drop = make_drop(a->f.drop_p, a->f.drop_seed);
   p.dout = a->dout; p.ld_dout = a->ld_dout; p.dqkv = a->dqkv; p.ld_dqkv = a->ld_dqkv;
   p.d_dense_bias = a->d_dense_bias; p.d_sp_table = a->d_sp_table; p.d_virt = a->d_virt;
   return dispatch<true>((hipStream_t)stream, p);

@@ -81,6 +81,32 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// ---------------------------------------------------------------- dropout RNG
+// Counter-based: the keep/drop decision of element `idx` of dropout site `seed` is a pure
+// function of (seed, idx), so backward regenerates the forward mask without storing it.
+__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t idx) {
+  uint32_t x = (uint32_t)idx ^ ((uint32_t)(idx >> 32) * 0x9E3779B1u) ^ (uint32_t)seed;
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  x += (uint32_t)(seed >> 32) * 0x85EBCA77u;
+  x ^= x >> 15; x *= 0x2c1b3c6dU; x ^= x >> 12; x *= 0x297a2d39U; x ^= x >> 15;
+  return x;
+}
+struct DropCfg {
+  uint64_t seed;
+  uint32_t thresh;   // drop when (hash >> 8) < thresh, thresh = p * 2^24
+  float inv_keep;    // 1 / (1 - p)
+};
+__device__ __forceinline__ float drop_scale(const DropCfg& d, uint64_t idx) {
+  return ((drop_hash(d.seed, idx) >> 8) >= d.thresh) ? d.inv_keep : 0.f;
+}
+static inline DropCfg make_drop(float p, uint64_t seed) {
+  DropCfg d;
+  d.seed = seed;
+  d.thresh = (uint32_t)(p * 16777216.0f);
+  d.inv_keep = 1.0f / (1.0f - p);
+  return d;
+}
+
 // ---------------------------------------------------------------- MFMA wrappers (16x16 tiles)
 // C/D layout (all dtypes): col = lane & 15, row = (lane >> 4) * 4 + reg.
 // f32:  A[row = lane&15][k = lane>>4],            B[k = lane>>4][col = lane&15]        (K = 4)

@@ -28,6 +28,7 @@ struct GemmParams {
   void* aux; int64_t ldaux;
   int split_k; int64_t k_chunk;
   int tiles_m, tiles_n;
+  DropCfg drop;
 };
 
 // ------------------------------------------------------------------ shared epilogue
@@ -42,6 +43,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t row,
     if (p.aux) v = to_f32(from_f32<TIn>(v));
     v = gelu_erf(v);
   }
+  if (p.epilogue & MDT_EPI_DROPOUT) v *= drop_scale(p.drop, (uint64_t)row * p.N + col);
   if (p.epilogue & MDT_EPI_DGELU) v *= gelu_erf_grad(to_f32(((const TIn*)p.aux)[row * p.ldaux + col]));
   if (p.epilogue & MDT_EPI_RESIDUAL) v += to_f32(((const TIn*)p.residual)[row * p.ldr + col]);
   TOut* c = (TOut*)p.C + row * p.ldc + col;
@@ -229,6 +231,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+    }
+    if (ep & MDT_EPI_DROPOUT) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= drop_scale(p.drop, (uint64_t)gr * p.N + gc + e);
     }
     if (ep & MDT_EPI_DGELU) {
       const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + gr * p.ldaux + gc);
@@ -485,6 +491,18 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(int64_t M, int64_t N, c
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(int64_t rows, int D, const T* x, int64_t ldx, T* y, int64_t ldy, DropCfg d) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4)
+    for (int c = lane; c < D; c += 64)
+      y[r * ldy + c] = from_f32<T>(to_f32(x[r * ldx + c]) * drop_scale(d, (uint64_t)r * D + c));
+}
+__global__ void dropout_mask_kernel(int64_t n, DropCfg d, uint8_t* mask) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    mask[i] = drop_scale(d, (uint64_t)i) != 0.f;
+}
+
 template <typename TS, typename TD>
 __global__ void cast_kernel(int64_t n, const TS* s, TD* d) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -558,7 +576,7 @@ using namespace mdt;
 extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int trans_b, int64_t M, int64_t N,
                         int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                         int epilogue, float alpha, const void* bias, const void* residual, int64_t ldr, void* aux,
-                        int64_t ldaux, int split_k) {
+                        int64_t ldaux, int split_k, float drop_p, uint64_t drop_seed) {
   MDT_CHECK_ARG(dtype == MDT_F32 || dtype == MDT_BF16, "mdt_gemm: bad dtype %d", dtype);
   MDT_CHECK_ARG(out_dtype == MDT_F32 || out_dtype == MDT_BF16, "mdt_gemm: bad out_dtype %d", out_dtype);
   MDT_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "mdt_gemm: negative shape");
@@ -571,13 +589,15 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   MDT_CHECK_ARG(dtype == MDT_BF16 || out_dtype == MDT_F32, "mdt_gemm: fp32 inputs need fp32 output");
   if (split_k < 1) split_k = 1;
   MDT_CHECK_ARG(split_k == 1 || (epilogue & MDT_EPI_ATOMIC), "mdt_gemm: split_k > 1 needs MDT_EPI_ATOMIC");
-  MDT_CHECK_ARG(split_k == 1 || !(epilogue & (MDT_EPI_BIAS | MDT_EPI_GELU | MDT_EPI_RESIDUAL | MDT_EPI_DGELU)),
+  MDT_CHECK_ARG(!(epilogue & MDT_EPI_DROPOUT) || (drop_p >= 0.f && drop_p < 1.f), "mdt_gemm: dropout p=%f out of [0,1)", drop_p);
+  MDT_CHECK_ARG(split_k == 1 || !(epilogue & (MDT_EPI_BIAS | MDT_EPI_GELU | MDT_EPI_RESIDUAL | MDT_EPI_DGELU | MDT_EPI_DROPOUT)),
                 "mdt_gemm: split_k > 1 supports only the plain accumulate epilogue");
   hipStream_t st = (hipStream_t)stream;
   GemmParams p;
   p.M = M; p.N = N; p.K = K; p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
   p.epilogue = epilogue; p.alpha = alpha; p.bias = bias; p.residual = residual; p.ldr = ldr;
   p.aux = aux; p.ldaux = ldaux; p.split_k = split_k;
+  p.drop = make_drop((epilogue & MDT_EPI_DROPOUT) ? drop_p : 0.f, drop_seed);
   // tile128 contract: bf16, output dims that are tiled along a contiguous axis must be
   // whole tiles, 16-B aligned rows.
   bool fast = dtype == MDT_BF16 && K > 0;
@@ -663,6 +683,27 @@ extern "C" int mdt_colsum(void* stream, int dtype, int64_t M, int64_t N, const v
   if (dtype == MDT_F32) hipLaunchKernelGGL((colsum_kernel<float, 256>), grid, 256, 0, st, M, N, (const float*)X, ldx, out, rows_per_block, row_weight);
   else hipLaunchKernelGGL((colsum_kernel<bf16_t, 256>), grid, 256, 0, st, M, N, (const bf16_t*)X, ldx, out, rows_per_block, row_weight);
   return check_launch("colsum");
+}
+
+extern "C" int mdt_dropout(void* stream, int dtype, int64_t rows, int D, const void* x, int64_t ldx, void* y, int64_t ldy,
+                           float p_, uint64_t seed) {
+  if (rows == 0 || D == 0) return MDT_OK;
+  MDT_CHECK_ARG(x && y && p_ >= 0.f && p_ < 1.f, "mdt_dropout: bad arguments (p=%f)", p_);
+  hipStream_t st = (hipStream_t)stream;
+  const DropCfg d = make_drop(p_, seed);
+  const unsigned grid = (unsigned)((rows + 3) / 4 > 8192 ? 8192 : (rows + 3) / 4);
+  if (dtype == MDT_F32) hipLaunchKernelGGL((dropout_kernel<float>), grid, 256, 0, st, rows, D, (const float*)x, ldx, (float*)y, ldy, d);
+  else if (dtype == MDT_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), grid, 256, 0, st, rows, D, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, d);
+  else MDT_UNSUPPORTED("mdt_dropout: dtype %d", dtype);
+  return check_launch("dropout");
+}
+
+extern "C" int mdt_dropout_mask(void* stream, int64_t n, float p_, uint64_t seed, uint8_t* mask) {
+  if (n == 0) return MDT_OK;
+  MDT_CHECK_ARG(mask && p_ >= 0.f && p_ < 1.f, "mdt_dropout_mask: bad arguments");
+  hipLaunchKernelGGL(dropout_mask_kernel, (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256), 256, 0,
+                     (hipStream_t)stream, n, make_drop(p_, seed), mask);
+  return check_launch("dropout_mask");
 }
 
 extern "C" int mdt_cast(void* stream, int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst) {

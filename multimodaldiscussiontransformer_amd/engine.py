@@ -44,6 +44,15 @@ class Tape:
         self.use_main_grad = use_main_grad
         self.tmp_grads = {}
         self.on_params_ready = on_params_ready     # DDP hook: called with the params an op just finished
+        self._seed_base = None
+        self._seed_ctr = 0
+
+    def next_seed(self) -> int:
+        """A fresh 63-bit dropout-site seed (CPU generator: follows torch.manual_seed, no device sync)."""
+        if self._seed_base is None:
+            self._seed_base = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self._seed_ctr += 1
+        return (self._seed_base + 0x9E3779B97F4A7C15 * self._seed_ctr) & 0x7FFFFFFFFFFFFFFF
 
     # -- gradient plumbing ------------------------------------------------------------
     def record(self, bwd: Callable[[], None]):
@@ -157,31 +166,41 @@ def _ln_bwd(tape, dy, x, w, b, mean, rstd, add=None):
 
 # ------------------------------------------------------------------------------------------
 # ops
-def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre_ln: bool, eps: float) -> Var:
+def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre_ln: bool, eps: float,
+                      p_hidden: float = 0.0, p_attn: float = 0.0, p_act: float = 0.0) -> Var:
     """One encoder block (post-LN: HF BertLayer / Graphormer layer; pre-LN: HF ViTLayer or
     Graphormer with --pre-layernorm).  7 GEMM-class launches + attention + 2 LayerNorms
-    forward; the adjoint below mirrors it with the residual adds folded into epilogues."""
+    forward; the adjoint below mirrors it with the residual adds folded into epilogues.
+    Dropout (training): ``p_attn`` on attention probabilities (inside the attention kernel),
+    ``p_hidden`` on the two dense outputs before their residual adds and ``p_act`` after GELU
+    (both in the GEMM epilogue); masks are regenerated in backward from per-site seeds."""
     xd = x.data
     kw = spec.kwargs()
+    s_attn, s_o, s_act, s_f2 = (tape.next_seed() for _ in range(4))
+    akw = dict(drop_p=p_attn, drop_seed=s_attn)
     if not pre_ln:
         qkv = ops.gemm(xd, P.qkv_w.data, bias=P.qkv_b.data)
-        ctx, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw)
-        t = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xd)
+        ctx, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw, **akw)
+        t = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xd, drop_p=p_hidden, drop_seed=s_o)
         a, m1, r1 = ops.layernorm_fwd(t, P.ln1_w.data, P.ln1_b.data, eps)
         u = torch.empty(a.shape[0], P.fc1_w.shape[0], dtype=a.dtype, device=a.device)
-        h = ops.gemm(a, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU)
-        y = ops.gemm(h, P.fc2_w.data, bias=P.fc2_b.data, residual=a)
+        h = ops.gemm(a, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU, drop_p=p_act, drop_seed=s_act)
+        y = ops.gemm(h, P.fc2_w.data, bias=P.fc2_b.data, residual=a, drop_p=p_hidden, drop_seed=s_f2)
         out, m2, r2 = ops.layernorm_fwd(y, P.ln2_w.data, P.ln2_b.data, eps)
     else:
         n1, m1, r1 = ops.layernorm_fwd(xd, P.ln1_w.data, P.ln1_b.data, eps)
         qkv = ops.gemm(n1, P.qkv_w.data, bias=P.qkv_b.data)
-        ctx, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw)
-        hmid = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xd)
+        ctx, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw, **akw)
+        hmid = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xd, drop_p=p_hidden, drop_seed=s_o)
         n2, m2, r2 = ops.layernorm_fwd(hmid, P.ln2_w.data, P.ln2_b.data, eps)
         u = torch.empty(n2.shape[0], P.fc1_w.shape[0], dtype=n2.dtype, device=n2.device)
-        f = ops.gemm(n2, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU)
-        out = ops.gemm(f, P.fc2_w.data, bias=P.fc2_b.data, residual=hmid)
+        f = ops.gemm(n2, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU, drop_p=p_act, drop_seed=s_act)
+        out = ops.gemm(f, P.fc2_w.data, bias=P.fc2_b.data, residual=hmid, drop_p=p_hidden, drop_seed=s_f2)
     o = Var(out)
+
+    def hdrop(g, seed):
+        """gradient w.r.t. a dense output that went through hidden dropout"""
+        return ops.dropout(g, p_hidden, seed) if p_hidden > 0 else g
 
     def attn_bwd(dctx):
         extra = {}
@@ -190,7 +209,7 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
                          d_virt=None if tape.pgrad(spec.virt) is None else tape.pgrad(spec.virt).view(-1))
         want_dense = spec.dense_bias_var is not None and spec.dense_bias_var.needs_grad
         dqkv, dbias = ops.attention_bwd(dctx, qkv, ctx, lse, spec.nseq, spec.S, spec.H, **kw,
-                                        want_dense_dbias=want_dense, **extra)
+                                        want_dense_dbias=want_dense, **extra, **akw)
         if want_dense:
             tape.add_grad(spec.dense_bias_var, dbias)
         return dqkv
@@ -201,13 +220,15 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         if g is None:
             return
         dy = _ln_bwd(tape, g, y, P.ln2_w, P.ln2_b, m2, r2)
-        wgrad(tape, dy, h, P.fc2_w, P.fc2_b)
-        du = ops.gemm(dy, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_DGELU)
+        dyd = hdrop(dy, s_f2)
+        wgrad(tape, dyd, h, P.fc2_w, P.fc2_b)
+        du = ops.gemm(dyd, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_DGELU, drop_p=p_act, drop_seed=s_act)
         wgrad(tape, du, a, P.fc1_w, P.fc1_b)
         da = ops.gemm(du, P.fc1_w.data, trans_b=True, residual=dy)
         dt_ = _ln_bwd(tape, da, t, P.ln1_w, P.ln1_b, m1, r1)
-        wgrad(tape, dt_, ctx, P.o_w, P.o_b)
-        dctx = ops.gemm(dt_, P.o_w.data, trans_b=True)
+        dtd = hdrop(dt_, s_o)
+        wgrad(tape, dtd, ctx, P.o_w, P.o_b)
+        dctx = ops.gemm(dtd, P.o_w.data, trans_b=True)
         dqkv = attn_bwd(dctx)
         wgrad(tape, dqkv, xd, P.qkv_w, P.qkv_b)
         if x.needs_grad:
@@ -220,13 +241,15 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         o.grad = None
         if g is None:
             return
-        wgrad(tape, g, f, P.fc2_w, P.fc2_b)
-        du = ops.gemm(g, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_DGELU)
+        gd = hdrop(g, s_f2)
+        wgrad(tape, gd, f, P.fc2_w, P.fc2_b)
+        du = ops.gemm(gd, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_DGELU, drop_p=p_act, drop_seed=s_act)
         wgrad(tape, du, n2, P.fc1_w, P.fc1_b)
         dn2 = ops.gemm(du, P.fc1_w.data, trans_b=True)
         dh = _ln_bwd(tape, dn2, hmid, P.ln2_w, P.ln2_b, m2, r2, add=g)
-        wgrad(tape, dh, ctx, P.o_w, P.o_b)
-        dctx = ops.gemm(dh, P.o_w.data, trans_b=True)
+        dhd = hdrop(dh, s_o)
+        wgrad(tape, dhd, ctx, P.o_w, P.o_b)
+        dctx = ops.gemm(dhd, P.o_w.data, trans_b=True)
         dqkv = attn_bwd(dctx)
         wgrad(tape, dqkv, n1, P.qkv_w, P.qkv_b)
         if x.needs_grad:
@@ -242,10 +265,11 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
     return o
 
 
-def attention_layer(tape: Tape, x: Var, qkv_w, qkv_b, o_w, o_b, spec: AttnSpec) -> Var:
+def attention_layer(tape: Tape, x: Var, qkv_w, qkv_b, o_w, o_b, spec: AttnSpec, p_attn: float = 0.0) -> Var:
     """Bare multi-head self-attention + output projection (modules/multihead_attention.py:91-214)."""
     xd = x.data
     kw = spec.kwargs()
+    kw.update(drop_p=p_attn, drop_seed=tape.next_seed())
     qkv = ops.gemm(xd, qkv_w.data, bias=None if qkv_b is None else qkv_b.data)
     ctx, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw)
     out = ops.gemm(ctx, o_w.data, bias=None if o_b is None else o_b.data)
@@ -286,6 +310,24 @@ def layernorm(tape: Tape, x: Var, w, b, eps: float) -> Var:
             return
         dx = _ln_bwd(tape, g, x.data, w, b, mean, rstd)
         tape.add_grad(x, dx)
+
+    tape.record(bwd)
+    return o
+
+
+def dropout(tape: Tape, x: Var, p: float) -> Var:
+    """Stand-alone inverted dropout (embedding / pooler dropouts); identity when p == 0."""
+    if p <= 0.0:
+        return x
+    seed = tape.next_seed()
+    o = Var(ops.dropout(x.data, p, seed))
+
+    def bwd():
+        g = o.grad
+        o.grad = None
+        if g is None:
+            return
+        tape.add_grad(x, ops.dropout(g, p, seed))
 
     tape.record(bwd)
     return o
@@ -448,7 +490,7 @@ def graph_node_features(tape: Tape, text: Var, text_row_of_node, in_degree, out_
     return o
 
 
-def classifier_head(tape: Tape, text: Var, M: int, St: int, nb: int, pool_w, pool_b, cls_w, cls_b) -> Var:
+def classifier_head(tape: Tape, text: Var, M: int, St: int, nb: int, pool_w, pool_b, cls_w, cls_b, p_drop: float = 0.0) -> Var:
     """models/multi_modal_discussion_transformer.py:265-274: the SAME pooler (dense + tanh on
     token 0) and classifier are applied to the text sequence ([CLS], row nb of each comment)
     and to the bottleneck sequence (bottleneck token 0, row 0); logits are their mean."""
@@ -458,7 +500,9 @@ def classifier_head(tape: Tape, text: Var, M: int, St: int, nb: int, pool_w, poo
     ops.row_axpby(rows, M, d_off=M, a=text.data, a_stride=St, a_off=0)
     pre = ops.gemm(rows, pool_w.data, bias=pool_b.data)
     pooled = ops.tanh_fwd(pre)
-    l2 = ops.gemm(pooled, cls_w.data, bias=cls_b.data)                       # [2M, C]
+    seed = tape.next_seed()
+    pooled_d = ops.dropout(pooled, p_drop, seed) if p_drop > 0 else pooled   # text_dropout, independent masks per branch
+    l2 = ops.gemm(pooled_d, cls_w.data, bias=cls_b.data)                     # [2M, C]
     C = l2.shape[1]
     logits = torch.empty(M, C, dtype=l2.dtype, device=l2.device)
     ops.row_axpby(logits, M, a=l2, alpha=0.5, b=l2, b_off=M, beta=0.5)
@@ -472,8 +516,10 @@ def classifier_head(tape: Tape, text: Var, M: int, St: int, nb: int, pool_w, poo
         dl2 = torch.empty_like(l2)
         ops.row_axpby(dl2, M, d_off=0, a=g, alpha=0.5)
         ops.row_axpby(dl2, M, d_off=M, a=g, alpha=0.5)
-        wgrad(tape, dl2, pooled, cls_w, cls_b)
+        wgrad(tape, dl2, pooled_d, cls_w, cls_b)
         dpooled = ops.gemm(dl2, cls_w.data, trans_b=True)
+        if p_drop > 0:
+            dpooled = ops.dropout(dpooled, p_drop, seed)
         dpre = ops.tanh_bwd(pooled, dpooled)
         wgrad(tape, dpre, rows, pool_w, pool_b)
         if text.needs_grad:

@@ -152,14 +152,14 @@ class GraphormerEncoder(nn.Module):
         """→ (logits [M, 2], global_embedding [B, D])."""
         ge = self.graph_encoder
         pb = packed_from_batched_data(batched_data)
-        if self.training and ge.text_dropout.p > 0:
-            raise NotImplementedError("head dropout > 0 in training mode is not implemented in the HIP path yet")
+        p_head = ge.text_dropout.p if self.training else 0.0
         nb = ge.num_bottle_neck
 
         def run(tape):
             text, glob = ge._fwd(tape, pb)
             logits = E.classifier_head(tape, text, pb.M, nb + pb.L, nb, ge.text_pooler.dense.weight,
-                                       ge.text_pooler.dense.bias, ge.node_classifier.weight, ge.node_classifier.bias)
+                                       ge.text_pooler.dense.bias, ge.node_classifier.weight, ge.node_classifier.bias,
+                                       p_drop=p_head)
             return logits, glob
 
         logits, glob = E.run_tape(run, [], ge.live_parameters(), use_main_grad=ge.use_main_grad, hook=ge.grad_ready_hook)

@@ -97,9 +97,14 @@ class BertLayer(nn.Module):
     def __init__(self, dim=768, heads=12, intermediate=3072, eps=1e-12):
         super().__init__()
         self.dim, self.heads, self.eps = dim, heads, eps
+        self.hidden_dropout_p, self.attention_dropout_p = 0.0, 0.0     # hidden_dropout_prob / attention_probs_dropout_prob
         self.attention = _BertAttention(dim, eps)
         self.intermediate = _Dense(dim, intermediate)
         self.output = _DenseLN(intermediate, dim, eps)
+
+    def drop_kwargs(self):
+        t = self.training
+        return dict(p_hidden=self.hidden_dropout_p if t else 0.0, p_attn=self.attention_dropout_p if t else 0.0)
 
     def block_params(self) -> BlockParams:
         a, o = self.attention, self.output
@@ -122,11 +127,16 @@ class ViTLayer(nn.Module):
     def __init__(self, dim=768, heads=12, intermediate=3072, eps=1e-12):
         super().__init__()
         self.dim, self.heads, self.eps = dim, heads, eps
+        self.hidden_dropout_p, self.attention_dropout_p = 0.0, 0.0
         self.attention = _ViTAttention(dim)
         self.intermediate = _Dense(dim, intermediate)
         self.output = _Dense(intermediate, dim)
         self.layernorm_before = nn.LayerNorm(dim, eps=eps)
         self.layernorm_after = nn.LayerNorm(dim, eps=eps)
+
+    def drop_kwargs(self):
+        t = self.training
+        return dict(p_hidden=self.hidden_dropout_p if t else 0.0, p_attn=self.attention_dropout_p if t else 0.0)
 
     def block_params(self) -> BlockParams:
         a = self.attention

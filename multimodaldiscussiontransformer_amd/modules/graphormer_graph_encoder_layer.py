@@ -57,13 +57,11 @@ class GraphormerGraphEncoderLayer(nn.Module):
                              self.fc1.bias, self.fc2.weight, self.fc2.bias, self.final_layer_norm.weight,
                              self.final_layer_norm.bias)
 
-    def _check_dropout(self):
-        if self.training and (self.dropout_p > 0 or self.activation_dropout_p > 0 or self.attention_dropout > 0):
-            raise NotImplementedError("dropout > 0 in training mode is not implemented in the HIP path yet")
-
     def _fwd(self, tape, x: E.Var, spec: E.AttnSpec) -> E.Var:
-        self._check_dropout()
-        return E.transformer_block(tape, x, self.block_params(), spec, pre_ln=self.pre_layernorm, eps=1e-5)
+        t = self.training
+        return E.transformer_block(tape, x, self.block_params(), spec, pre_ln=self.pre_layernorm, eps=1e-5,
+                                   p_hidden=self.dropout_p if t else 0.0, p_attn=self.attention_dropout if t else 0.0,
+                                   p_act=self.activation_dropout_p if t else 0.0)
 
     def forward(self, x: torch.Tensor, self_attn_bias: Optional[torch.Tensor] = None,
                 self_attn_mask: Optional[torch.Tensor] = None, self_attn_padding_mask: Optional[torch.Tensor] = None):

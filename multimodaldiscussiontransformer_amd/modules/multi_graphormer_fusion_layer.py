@@ -49,11 +49,11 @@ class GraphFusionLayer(nn.Module):
         if vit is not None:
             E.rows_mix(tape, vit, text, I * nb, alpha=1.0, beta=0.0, d_idx=vit_bn_rows, s_idx=img_text_bn_rows)
         spec_t = E.AttnSpec(nseq=M, S=St, H=be.heads, key_mask=text_mask_u8)
-        text_out = E.transformer_block(tape, text, be.block_params(), spec_t, pre_ln=False, eps=be.eps)
+        text_out = E.transformer_block(tape, text, be.block_params(), spec_t, pre_ln=False, eps=be.eps, **be.drop_kwargs())
         vit_out = None
         if vit is not None:
             spec_v = E.AttnSpec(nseq=I, S=Sv, H=ve.heads)
-            vit_out = E.transformer_block(tape, vit, ve.block_params(), spec_v, pre_ln=True, eps=ve.eps)
+            vit_out = E.transformer_block(tape, vit, ve.block_params(), spec_v, pre_ln=True, eps=ve.eps, **ve.drop_kwargs())
             E.rows_mix(tape, text_out, vit_out, I * nb, alpha=0.5, beta=0.5, d_idx=img_text_bn_rows, s_idx=vit_bn_rows)
         return text_out, vit_out
 

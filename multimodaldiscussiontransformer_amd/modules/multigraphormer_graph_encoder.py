@@ -150,6 +150,9 @@ class MultiGraphormerGraphEncoder(nn.Module):
             vit_model.encoder.layer = vit_model.encoder.layer[:-num_fusion_layers]
             bert_other = list(bert_model.encoder.layer[-num_fusion_layers:])
             bert_model.encoder.layer = bert_model.encoder.layer[:-num_fusion_layers]
+        for lyr in list(vit_model.encoder.layer) + vit_other + list(bert_model.encoder.layer) + bert_other:
+            lyr.hidden_dropout_p = activation_dropout            # hidden_dropout_prob=activation_dropout (:238,:243)
+            lyr.attention_dropout_p = attention_dropout          # attention_probs_dropout_prob=attention_dropout
         node_classifier = nn.Linear(bc["dim"], 2)       # BertForSequenceClassification.classifier, num_labels = 2
         nn.init.normal_(node_classifier.weight, 0.0, 0.02)
         nn.init.zeros_(node_classifier.bias)
@@ -192,9 +195,8 @@ class MultiGraphormerGraphEncoder(nn.Module):
     # ------------------------------------------------------------------ tape-level forward
     def _fwd(self, tape, pb: PackedBatch):
         """→ (text buffer Var [M*(nb+L), D], global embedding Var [B, D])."""
-        if self.training and (self.dropout_p > 0 or self.attention_dropout_p > 0 or self.activation_dropout_p > 0):
-            raise NotImplementedError("dropout > 0 in training mode is not implemented in the HIP path yet; "
-                                      "build the model with --dropout 0 --attention-dropout 0 --act-dropout 0")
+        tr = self.training
+        p_emb = self.activation_dropout_p if tr else 0.0     # HF hidden_dropout_prob := act_dropout (:238,:243)
         nb = self.num_bottle_neck
         ix = self._indices(pb)
         St, Sv, P = ix["St"], ix["Sv"], ix["P"]
@@ -203,18 +205,21 @@ class MultiGraphormerGraphEncoder(nn.Module):
         e = tm.embeddings
         emb = E.bert_embeddings(tape, pb.ids, pb.types, e.word_embeddings.weight, e.position_embeddings.weight,
                                 e.token_type_embeddings.weight)
-        text = E.layernorm(tape, emb, e.LayerNorm.weight, e.LayerNorm.bias, tm.eps)
+        text = E.dropout(tape, E.layernorm(tape, emb, e.LayerNorm.weight, e.LayerNorm.bias, tm.eps), p_emb)
         spec0 = E.AttnSpec(nseq=M, S=Lq, H=tm.heads, key_mask=pb.text_mask)
         for layer in tm.encoder.layer:
-            text = E.transformer_block(tape, text, layer.block_params(), spec0, pre_ln=False, eps=tm.eps)
+            text = E.transformer_block(tape, text, layer.block_params(), spec0, pre_ln=False, eps=tm.eps,
+                                       **layer.drop_kwargs())
         vit = None
         if I > 0:
             ve = vm.embeddings
             v = E.vit_embeddings(tape, pb.images, ve.patch_embeddings.projection.weight, ve.patch_embeddings.projection.bias,
                                  ve.cls_token, ve.position_embeddings, vm.patch)
+            v = E.dropout(tape, v, p_emb)
             specv = E.AttnSpec(nseq=I, S=P, H=vm.heads)
             for layer in vm.encoder.layer:
-                v = E.transformer_block(tape, v, layer.block_params(), specv, pre_ln=True, eps=vm.eps)
+                v = E.transformer_block(tape, v, layer.block_params(), specv, pre_ln=True, eps=vm.eps,
+                                        **layer.drop_kwargs())
             v = E.layernorm(tape, v, vm.layernorm.weight, vm.layernorm.bias, vm.eps)      # quirk 5: final LN mid-network
             vit = E.expand_sequences(tape, v, I, P, nb, None)
         text = E.expand_sequences(tape, text, M, Lq, nb, self.bottle_neck.weight)
@@ -226,6 +231,7 @@ class MultiGraphormerGraphEncoder(nn.Module):
                                   M, pb.deg_scatter, pb.deg_scatter)
         if self.emb_layer_norm is not None:
             x = E.layernorm(tape, x, self.emb_layer_norm.weight, self.emb_layer_norm.bias, 1e-5)
+        x = E.dropout(tape, x, self.dropout_p if tr else 0.0)          # self.dropout_module(x)  (:403)
         gab = self.graph_attn_bias
         hd = self.embedding_dim // self.num_graph_heads
         gspec = E.AttnSpec(nseq=B, S=T, H=self.num_graph_heads, scale=hd ** -0.5, attn_bias=pb.attn_bias,

@@ -71,7 +71,9 @@ class MultiheadAttention(QKVFusedMixin, nn.Module):
 
     # tape-level ------------------------------------------------------------------------
     def _fwd(self, tape, x: E.Var, spec: E.AttnSpec) -> E.Var:
-        return E.attention_layer(tape, x, self.qkv_weight, self.qkv_bias, self.out_proj.weight, self.out_proj.bias, spec)
+        p = self.dropout_p if self.training else 0.0
+        return E.attention_layer(tape, x, self.qkv_weight, self.qkv_bias, self.out_proj.weight, self.out_proj.bias, spec,
+                                 p_attn=p)
 
     # public (reference signature) ------------------------------------------------------
     def forward(self, query, key: Optional[Tensor], value: Optional[Tensor], attn_bias: Optional[Tensor],
@@ -82,8 +84,6 @@ class MultiheadAttention(QKVFusedMixin, nn.Module):
         if need_head_weights or before_softmax or attn_mask is not None:
             raise NotImplementedError("the fused kernel never materialises attention weights; "
                                       "need_head_weights / before_softmax / attn_mask are unsupported")
-        if self.training and self.dropout_p > 0:
-            raise NotImplementedError("attention dropout > 0 is not implemented in the HIP path yet")
         tgt_len, bsz, embed_dim = query.size()
         assert embed_dim == self.embed_dim, f"query dim {embed_dim} != {self.embed_dim}"
         if key_padding_mask is not None and key_padding_mask.dim() == 0:

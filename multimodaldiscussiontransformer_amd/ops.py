@@ -11,13 +11,14 @@ from typing import Optional
 import torch
 
 from . import _lib as L
-from ._lib import EPI_ACCUM, EPI_ATOMIC, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_RESIDUAL, check, dt, lib, ptr, stream
+from ._lib import (EPI_ACCUM, EPI_ATOMIC, EPI_BIAS, EPI_DGELU, EPI_DROPOUT, EPI_GELU, EPI_RESIDUAL, check, dt, lib,
+                   ptr, stream)
 
 __all__ = [
     "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "graph_attn_bias",
     "row_axpby", "row_scatter_add", "bert_embed_sum", "vit_patchify", "vit_assemble", "graph_node_feature",
-    "tanh_fwd", "tanh_bwd", "node_ce", "cast", "transpose2d",
-    "EPI_BIAS", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_ACCUM", "EPI_ATOMIC",
+    "tanh_fwd", "tanh_bwd", "node_ce", "cast", "transpose2d", "dropout", "dropout_mask",
+    "EPI_BIAS", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_ACCUM", "EPI_ATOMIC", "EPI_DROPOUT",
 ]
 
 
@@ -27,7 +28,8 @@ def _2d(t: torch.Tensor):
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out: Optional[torch.Tensor] = None,
-         out_dtype=None, bias=None, residual=None, aux=None, epilogue=0, alpha=1.0, split_k=1) -> torch.Tensor:
+         out_dtype=None, bias=None, residual=None, aux=None, epilogue=0, alpha=1.0, split_k=1, drop_p=0.0,
+         drop_seed=0) -> torch.Tensor:
     """out[M,N] = epilogue(alpha * op(a) @ op(b)); b is [N,K] unless trans_b (then [K,N])."""
     lda, ldb = _2d(a), _2d(b)
     M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
@@ -46,10 +48,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
         assert residual.dtype == a.dtype and residual.shape == (M, N)
     if aux is not None:
         assert aux.dtype == a.dtype and aux.shape == (M, N)
+    if drop_p > 0.0:
+        epilogue |= EPI_DROPOUT
     check(lib.mdt_gemm(stream(), dt(a), dt(out), int(trans_a), int(trans_b), M, N, K, ptr(a), lda, ptr(b), ldb,
                        ptr(out), _2d(out), epilogue, float(alpha), ptr(bias), ptr(residual),
                        _2d(residual) if residual is not None else 0, ptr(aux), _2d(aux) if aux is not None else 0,
-                       int(split_k)), "mdt_gemm")
+                       int(split_k), float(drop_p), int(drop_seed)), "mdt_gemm")
     return out
 
 
@@ -85,8 +89,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, add=None, dgamma=None, dbeta=None, d
 
 
 def _attn_args(qkv, out, lse, nseq, S, H, hd, seq_stride, pos_stride, scale, key_mask, dense_bias, attn_bias,
-               spatial_pos, sp_table, virt, key_pad):
+               spatial_pos, sp_table, virt, key_pad, drop_p=0.0, drop_seed=0):
     a = L.AttnFwdArgs()
+    a.drop_p, a.drop_seed = float(drop_p), int(drop_seed)
     a.dtype = dt(qkv)
     a.nseq, a.S, a.H, a.hd = nseq, S, H, hd
     a.seq_stride, a.pos_stride, a.scale = seq_stride, pos_stride, float(scale)
@@ -108,7 +113,7 @@ def _attn_args(qkv, out, lse, nseq, S, H, hd, seq_stride, pos_stride, scale, key
 
 
 def attention_fwd(qkv, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None, key_mask=None, dense_bias=None,
-                  attn_bias=None, spatial_pos=None, sp_table=None, virt=None, key_pad=None):
+                  attn_bias=None, spatial_pos=None, sp_table=None, virt=None, key_pad=None, drop_p=0.0, drop_seed=0):
     """qkv [rows, 3*D] → (out [rows, D], lse f32[nseq, H, S])."""
     D = qkv.shape[1] // 3
     hd = D // H
@@ -116,21 +121,21 @@ def attention_fwd(qkv, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None,
     lse = torch.empty(nseq, H, S, dtype=torch.float32, device=qkv.device)
     a = _attn_args(qkv, out, lse, nseq, S, H, hd, S if seq_stride is None else seq_stride, pos_stride,
                    hd ** -0.5 if scale is None else scale, key_mask, dense_bias, attn_bias, spatial_pos, sp_table,
-                   virt, key_pad)
+                   virt, key_pad, drop_p, drop_seed)
     check(lib.mdt_attention_fwd(stream(), C.byref(a)), "mdt_attention_fwd")
     return out, lse
 
 
 def attention_bwd(dout, qkv, out, lse, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None, key_mask=None,
                   dense_bias=None, attn_bias=None, spatial_pos=None, sp_table=None, virt=None, key_pad=None,
-                  want_dense_dbias=False, d_sp_table=None, d_virt=None):
+                  want_dense_dbias=False, d_sp_table=None, d_virt=None, drop_p=0.0, drop_seed=0):
     D = qkv.shape[1] // 3
     hd = D // H
     dqkv = torch.empty_like(qkv)
     b = L.AttnBwdArgs()
     b.f = _attn_args(qkv, out, lse, nseq, S, H, hd, S if seq_stride is None else seq_stride, pos_stride,
                      hd ** -0.5 if scale is None else scale, key_mask, dense_bias, attn_bias, spatial_pos, sp_table,
-                     virt, key_pad)
+                     virt, key_pad, drop_p, drop_seed)
     b.dout, b.ld_dout = ptr(dout), _2d(dout)
     b.dqkv, b.ld_dqkv = ptr(dqkv), _2d(dqkv)
     dbias = None
@@ -243,3 +248,18 @@ def transpose2d(src, dtype=None):
     check(lib.mdt_transpose2d(stream(), dt(src), dt(dst), src.shape[0], src.shape[1], ptr(src), _2d(src), ptr(dst),
                               _2d(dst)), "mdt_transpose2d")
     return dst
+
+
+def dropout(x, p, seed, out=None):
+    """y = x * keep(seed, row*D + col) / (1 - p); the same call on a gradient is the backward."""
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.mdt_dropout(stream(), dt(x), x.shape[0], x.shape[1], ptr(x), _2d(x), ptr(out), _2d(out), float(p), int(seed)),
+          "mdt_dropout")
+    return out
+
+
+def dropout_mask(n, p, seed, device="cuda"):
+    m = torch.empty(n, dtype=torch.uint8, device=device)
+    check(lib.mdt_dropout_mask(stream(), n, float(p), int(seed), ptr(m)), "mdt_dropout_mask")
+    return m
