@@ -9,7 +9,8 @@ already resident in HBM: encoder (BERT / ViT blocks, bottleneck fusion, Graphorm
 → head → weighted CE → backward → (N > 1) RCCL gradient all-reduce overlapped with backward.
 Workload (BASELINE.json configs[1]): mDT-base — BERT-base + ViT-B/16 split 6 + 6, 6 executed
 graph layers, D 768, 12 heads, nb 4, L 100 — on 32 bushy 64-comment trees per GPU with 25 % image
-comments, bf16 activations / weights, fp32 softmax, LayerNorm statistics and gradient arena.
+comments, bf16 activations / weights, fp32 softmax, LayerNorm statistics and gradient arena,
+dropout ON at the reference launch's rates (0.4 / 0.3 / 0.3; --dropout 0 ... turns it off).
 Weak scaling: every rank processes its own 32 trees, no data-path collective except the
 gradient all-reduce.
 
@@ -43,7 +44,8 @@ def base_args(a):
         num_atoms=512 * 9, num_in_degree=512, num_out_degree=512, num_edges=512 * 3, num_spatial=512, num_edge_dis=128,
         edge_type="multi_hop", multi_hop_max_dist=5, num_bottleneck_tokens=4, num_fusion_layers=a.num_fusion_layers,
         num_fusion_stack=1, num_graph_stack=1, encoder_layers=4, encoder_embed_dim=768, encoder_ffn_embed_dim=768,
-        encoder_attention_heads=12, dropout=0.0, attention_dropout=0.0, act_dropout=0.0, encoder_normalize_before=True,
+        encoder_attention_heads=12, dropout=a.dropout, attention_dropout=a.attention_dropout, act_dropout=a.act_dropout,
+        encoder_normalize_before=True,
         pre_layernorm=False, apply_graphormer_init=False, activation_fn="gelu",
         freeze_initial_encoders=a.freeze_initial_encoders, share_encoder_input_output_embed=False, max_nodes=10000,
         num_classes=1)
@@ -155,6 +157,9 @@ def main():
     ap.add_argument("--image-frac", type=float, default=0.25)
     ap.add_argument("--num_fusion_layers", type=int, default=5)
     ap.add_argument("--freeze_initial_encoders", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.4, help="reference launch: run_train.sh:37")
+    ap.add_argument("--attention-dropout", type=float, default=0.3)
+    ap.add_argument("--act-dropout", type=float, default=0.3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
@@ -250,7 +255,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "mDT-base (BERT-base + ViT-B/16 split 6+6, 6 executed graph layers, D768 H12 nb4 L100), "
                                    f"{args.trees} bushy {args.nodes}-comment trees per GPU, {int(args.image_frac * 100)}% image comments, "
-                                   "random-init weights, dropout 0, no optimizer step",
+                                   f"random-init weights, dropout {args.dropout}/{args.attention_dropout}/{args.act_dropout} (run_train.sh:37), "
+                                   "no optimizer step",
                        "trees_per_gpu": args.trees, "comments_per_step_per_gpu": comments_per_step,
                        "parallelism": f"dp{world}", "frozen_initial_encoders": bool(args.freeze_initial_encoders)},
             "model_tflops": round(value * 3 * fpc / 1e12, 1),
