@@ -136,7 +136,7 @@ template <typename T>
 __device__ __forceinline__ int scratch_ld(int s_pad32) { return s_pad32 + (std::is_same<T, float>::value ? 1 : 8); }
 
 // ---------------------------------------------------------------------------- forward
-template <typename T, int HD, int NT, bool STRUCT>
+template <typename T, int HD, int NT, bool STRUCT, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
   constexpr bool BF = !std::is_same<T, float>::value;
   constexpr int KS = MM<T>::KS;
@@ -231,16 +231,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
         a.lse[((int64_t)seq * a.H + h) * S + q] = (sum[r] > 0.f) ? mx[r] + __logf(sum[r]) : -INFINITY;
       sum[r] = (sum[r] > 0.f) ? 1.0f / sum[r] : 0.f;
     }
-    const bool dropping = a.drop_p > 0.f;
-    const DropCfg dc = P.drop;
+    const uint32_t drop_base = (uint32_t)((seq * a.H + h) * S) * (uint32_t)S;   // host guarantees nseq*H*S*S < 2^32
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float pv = sc[t][r] * sum[r];
-        if (dropping) {
+        if constexpr (DROP) {
           const int q = q0 + (lane >> 4) * 4 + r, key = t * 16 + (lane & 15);
-          pv *= drop_scale(dc, (((uint64_t)seq * a.H + h) * S + q) * S + key);
+          pv *= drop_scale(P.drop, (uint64_t)(drop_base + (uint32_t)(q * S + key)));
         }
         scratch[((lane >> 4) * 4 + r) * sld + t * 16 + (lane & 15)] = from_f32<T>(pv);
       }
@@ -271,7 +270,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
 // Pass A (per 16-query tile): S, P, dP = dO V^T, delta = rowsum(P*dP), dS = P*(dP-delta),
 //                             dQ = scale * dS K, bias gradients.
 // Pass B (per 16-key tile):   S^T, P^T, dP^T = V dO^T, dS^T, dV = P^T dO, dK = scale * dS^T Q.
-template <typename T, int HD, int NT, bool STRUCT>
+template <typename T, int HD, int NT, bool STRUCT, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams P) {
   constexpr bool BF = !std::is_same<T, float>::value;
   constexpr int KS = MM<T>::KS;
@@ -326,8 +325,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams P) {
   __syncthreads();
 
   BiasCtx bc{seq, h, S, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
-  const bool dropping = a.drop_p > 0.f;
-  const DropCfg dc = P.drop;
+  const uint32_t drop_base = (uint32_t)((seq * a.H + h) * S) * (uint32_t)S;   // host guarantees nseq*H*S*S < 2^32
   const Src<T> gQ{qkv, tld, S};
   const Src<T> gDO{dout, dld, S};
   const int n_t = (S + 15) >> 4;
@@ -367,7 +365,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams P) {
           const float l = s_lse[q];
           const float p = (v == -INFINITY || l == -INFINITY || !qok) ? 0.f : __expf(v - l);
           sc[t][r] = p;
-          if (dropping) dp[t][r] *= drop_scale(dc, (((uint64_t)seq * a.H + h) * S + q) * S + key);   // dP = dD * M / (1-p)
+          if constexpr (DROP) dp[t][r] *= drop_scale(P.drop, (uint64_t)(drop_base + (uint32_t)(q * S + key)));   // dP = dD * M / (1-p)
           del[r] += p * dp[t][r];
         }
       }
@@ -479,8 +477,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams P) {
           const float p = (v == -INFINITY || l == -INFINITY || !qok) ? 0.f : __expf(v - l);
           float ds = dp[t][r];
           float pd = p;
-          if (dropping) {
-            const float m = drop_scale(dc, (((uint64_t)seq * a.H + h) * S + qc) * S + key);
+          if constexpr (DROP) {
+            const float m = drop_scale(P.drop, (uint64_t)(drop_base + (uint32_t)(qc * S + key)));
             ds *= m;                          // dP^T = dD^T * M / (1-p)
             pd *= m;                          // D^T  = P^T * M / (1-p)
           }
@@ -550,13 +548,13 @@ __global__ void graph_attn_bias_kernel(int nseq, int S, int H, const float* attn
   }
 }
 
-template <typename T, int HD, int NT, bool STRUCT>
+template <typename T, int HD, int NT, bool STRUCT, bool DROP>
 static int launch_fwd(hipStream_t st, const AttnParams& p) {
   constexpr int s_pad32 = (NT * 16 + 31) & ~31;
   constexpr bool BF = !std::is_same<T, float>::value;
   const int sld = s_pad32 + (BF ? 8 : 1);
   size_t lds = (size_t)4 * 16 * sld * sizeof(T) + (BF ? (size_t)2 * s_pad32 * IMG_LD * 2 : 0);
-  auto kern = attn_fwd_kernel<T, HD, NT, STRUCT>;
+  auto kern = attn_fwd_kernel<T, HD, NT, STRUCT, DROP>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       (void)hipGetLastError();
@@ -568,7 +566,7 @@ static int launch_fwd(hipStream_t st, const AttnParams& p) {
   return check_launch("attention_fwd");
 }
 
-template <typename T, int HD, int NT, bool STRUCT>
+template <typename T, int HD, int NT, bool STRUCT, bool DROP>
 static int launch_bwd(hipStream_t st, const AttnParams& p) {
   constexpr int s_pad32 = (NT * 16 + 31) & ~31;
   constexpr bool BF = !std::is_same<T, float>::value;
@@ -576,7 +574,7 @@ static int launch_bwd(hipStream_t st, const AttnParams& p) {
   const int nhist = STRUCT ? ((p.f.num_spatial + 1 + 3) & ~3) : 0;
   size_t lds = (size_t)(2 * s_pad32 + nhist) * 4 + (size_t)4 * 16 * sld * sizeof(T) +
                (BF ? (size_t)2 * s_pad32 * IMG_LD * 2 : 0);
-  auto kern = attn_bwd_kernel<T, HD, NT, STRUCT>;
+  auto kern = attn_bwd_kernel<T, HD, NT, STRUCT, DROP>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       (void)hipGetLastError();
@@ -591,8 +589,11 @@ static int launch_bwd(hipStream_t st, const AttnParams& p) {
 template <typename T, int HD, bool STRUCT, bool BWD>
 static int dispatch_nt(hipStream_t st, const AttnParams& p) {
   const int nt = (p.f.S + 15) / 16;
-#define ATT_CASE(N_)                                                              \
-  if (nt <= N_) return BWD ? launch_bwd<T, HD, N_, STRUCT>(st, p) : launch_fwd<T, HD, N_, STRUCT>(st, p);
+#define ATT_CASE(N_)                                                                              \
+  if (nt <= N_) {                                                                                 \
+    if (p.f.drop_p > 0.f) return BWD ? launch_bwd<T, HD, N_, STRUCT, true>(st, p) : launch_fwd<T, HD, N_, STRUCT, true>(st, p); \
+    return BWD ? launch_bwd<T, HD, N_, STRUCT, false>(st, p) : launch_fwd<T, HD, N_, STRUCT, false>(st, p);                    \
+  }
   ATT_CASE(2) ATT_CASE(5) ATT_CASE(7) ATT_CASE(9) ATT_CASE(13) ATT_CASE(16)
 #undef ATT_CASE
   set_error("attention: S=%d exceeds the 256-token limit of the single-pass kernel", p.f.S);
@@ -623,6 +624,9 @@ static int check_args(const mdt_attn_fwd_args& a) {
   if (a.dtype == MDT_BF16)
     MDT_CHECK_ARG(a.ld_qkv % 8 == 0 && ((uintptr_t)a.qkv & 15) == 0, "attention(bf16): qkv must be 16-byte aligned rows");
   if (a.attn_bias) MDT_CHECK_ARG(a.spatial_pos && a.sp_table && a.virt && a.num_spatial > 0, "attention: incomplete structural bias");
+  MDT_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f, "attention: dropout p=%f out of [0,1)", a.drop_p);
+  MDT_CHECK_ARG(a.drop_p == 0.f || (uint64_t)a.nseq * a.H * a.S * a.S < (1ull << 32),
+                "attention: dropout counters are 32-bit (nseq*H*S*S must stay below 2^32)");
   return MDT_OK;
 }
 

@@ -440,6 +440,116 @@ __global__ __launch_bounds__(512) void gemm_bf16_tile256(GemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------ bf16 256x256x64, ping-pong
+// Same tile and staging as gemm_bf16_tile256<BN=256>, but the K-tile is cut into four phases of
+// 16 MFMAs (k-step x row-half of the wave's 128x64 block) and each phase into a READ segment
+// (ds_read of the phase's fragments, LDS-DMA issue of the next K-tile) and an MFMA segment,
+// separated by s_barrier.  Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one of
+// its two resident waves is in an MFMA segment while the other fetches operands: the matrix
+// pipe no longer idles while both waves wait for LDS (MI355X_MICROARCH.md "Two waves per SIMD").
+//   barrier pairing: early group's n-th barrier == late group's (n-1)-th.
+//   RAW: every wave drains its own LDS-DMA loads of tile kt+1 (vmcnt(0)) before the barrier that
+//        closes its READ segment 3 of tile kt; the first read of tile kt+1 by anyone follows the
+//        barrier that pairs those two.  WAR: the loads of tile kt+1 are issued in READ 0 of tile
+//        kt, after the barrier behind which the late group completed (lgkmcnt(0)) its last reads
+//        of tile kt-1.
+template <typename TOut, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
+  constexpr int BM = 256, BN = 256;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const bool late = wave >= 4;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * p.k_chunk;
+  const int64_t kend = (kbeg + p.k_chunk < p.K) ? kbeg + p.k_chunk : p.K;
+  const int nk = (int)((kend - kbeg + T_BK - 1) / T_BK);
+
+  const int64_t lda_b = p.lda * 2, ldb_b = p.ldb * 2;
+  const char* a_base;
+  const char* b_base;
+  int64_t a_bytes, b_bytes;
+  if constexpr (!A_KM) { a_base = (const char*)p.A + m0 * lda_b; a_bytes = (p.M - m0) * lda_b; }
+  else { a_base = (const char*)p.A + kbeg * lda_b; a_bytes = (kend - kbeg) * lda_b; }
+  if constexpr (!B_KM) { b_base = (const char*)p.B + n0 * ldb_b; b_bytes = (p.N - n0) * ldb_b; }
+  else { b_base = (const char*)p.B + kbeg * ldb_b; b_bytes = (kend - kbeg) * ldb_b; }
+  const unsigned a_rec = (unsigned)(a_bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : a_bytes);
+  const unsigned b_rec = (unsigned)(b_bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : b_bytes);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, a_rec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, b_rec, 0x00020000);
+  const int64_t a_k0 = A_KM ? 0 : kbeg, b_k0 = B_KM ? 0 : kbeg;
+  const int a_col0 = A_KM ? (int)m0 : 0, b_col0 = B_KM ? (int)n0 : 0;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int kt) {
+    char* st = smem + (kt & 1) * STAGE;
+    stage_tile<A_KM, BM, 8>(rsA, lda_b, a_k0 + (int64_t)kt * T_BK, a_col0, st, wave, lane);
+    stage_tile<B_KM, BN, 8>(rsB, ldb_b, b_k0 + (int64_t)kt * T_BK, b_col0, st + A_BYTES, wave, lane);
+  };
+  if (nk > 0) issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (late) __builtin_amdgcn_s_barrier();      // the stagger: waves 4-7 run one segment behind
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* cur = smem + (kt & 1) * STAGE;
+    bf16x8 b[4];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      const int ks = ph >> 1, mh = ph & 1;
+      // ---------------- READ segment
+      bf16x8 a[4];
+      if (mh == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = load_frag<B_KM, BN>(cur + A_BYTES, wc * 64 + j * 16, ks, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = load_frag<A_KM, BM>(cur, wr * 128 + mh * 64 + i * 16, ks, lane);
+      if (ph == 0 && kt + 1 < nk) issue(kt + 1);
+      if (ph == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- MFMA segment
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[mh * 4 + i][j] = mfma_bf16(a[i], b[j], acc[mh * 4 + i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!late) __builtin_amdgcn_s_barrier();     // equalise the barrier count of the two groups
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f32x4 blk[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) blk[i][j] = acc[h * 4 + i][j];
+    tile_epilogue<TOut>(p, blk, smem, wave, lane, m0 + wr * 128 + h * 64, n0 + wc * 64);
+  }
+}
+
 // ------------------------------------------------------------------ helpers
 template <typename TIn, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void colsum_kernel(int64_t M, int64_t N, const TIn* X, int64_t ldx, float* out,
@@ -569,6 +679,32 @@ static int launch_tile256(hipStream_t st, const GemmParams& p, int ta, int tb) {
   return check_launch("gemm_bf16_tile256");
 }
 
+template <typename TOut>
+static int launch_pp256(hipStream_t st, const GemmParams& p, int ta, int tb) {
+  dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)p.split_k);
+  const size_t lds = (size_t)2 * 512 * 128;
+#define LPP(A_, B_)                                                                                          \
+  {                                                                                                          \
+    auto kern = gemm_bf16_pp256<TOut, A_, B_>;                                                               \
+    static bool attr_set = false;                                                                            \
+    if (!attr_set) {                                                                                         \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+        (void)hipGetLastError();                                                                             \
+        set_error("gemm_bf16_pp256: cannot reserve %zu bytes of LDS", lds);                                  \
+        return MDT_ERR_LAUNCH;                                                                               \
+      }                                                                                                      \
+      attr_set = true;                                                                                       \
+    }                                                                                                        \
+    hipLaunchKernelGGL(kern, grid, 512, lds, st, p);                                                         \
+  }
+  if (!ta && !tb) LPP(false, false)
+  else if (!ta && tb) LPP(false, true)
+  else if (ta && !tb) LPP(true, false)
+  else LPP(true, true)
+#undef LPP
+  return check_launch("gemm_bf16_pp256");
+}
+
 }  // namespace mdt
 
 using namespace mdt;
@@ -637,9 +773,12 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
       use256x256 = m256 && n256 && !strcmp(force, "256x256");
       use256x128 = m256 && !strcmp(force, "256x128");
     }
-    if (use256x256) {
+    if (use256x256 || (force && m256 && n256 && !strcmp(force, "pp"))) {
       p.tiles_m = (int)((M + 255) / 256);
       p.tiles_n = (int)(N / 256);
+      const bool pp = force ? !strcmp(force, "pp") : (getenv("MDT_GEMM_NO_PP") == nullptr);
+      if (pp) return out_dtype == MDT_F32 ? launch_pp256<float>(st, p, trans_a, trans_b)
+                                          : launch_pp256<bf16_t>(st, p, trans_a, trans_b);
       return out_dtype == MDT_F32 ? launch_tile256<float, 256, 2, 4, 2>(st, p, trans_a, trans_b)
                                   : launch_tile256<bf16_t, 256, 2, 4, 2>(st, p, trans_a, trans_b);
     }

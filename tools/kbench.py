@@ -26,7 +26,7 @@ def main():
     bf = torch.bfloat16
     M = 212992
     import os
-    for force in ("128", "256x128", "256x256", None):
+    for force in ("256x256", "pp"):
         if force is None:
             os.environ.pop("MDT_GEMM_TILE", None)
         else:
