@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmdt_hip.so")
-SOURCES = ["gemm.hip", "layernorm.hip", "attention.hip", "rowops.hip", "host.cpp"]
+SOURCES = ["gemm.hip", "layernorm.hip", "attention.hip", "attention_v2.hip", "rowops.hip", "host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-ffp-contract=off"]
 
 
@@ -24,7 +24,8 @@ def build(verbose: bool = False, force: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "mdt_hip.h")]
+    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "attention_common.hpp"),
+               os.path.join(HERE, "..", "include", "mdt_hip.h")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -17,17 +17,11 @@
 // BertLayer / ViTLayer (call sites modules/multi_graphormer_fusion_layer.py:94-96,138-146).
 #include <type_traits>
 
-#include "common.hpp"
+#include <stdlib.h>
+
+#include "attention_common.hpp"
 
 namespace mdt {
-
-struct AttnParams {
-  mdt_attn_fwd_args f;
-  DropCfg drop;
-  const void* dout; int64_t ld_dout;
-  void* dqkv; int64_t ld_dqkv;
-  float* d_dense_bias; float* d_sp_table; float* d_virt;
-};
 
 template <typename T> struct MM;
 template <> struct MM<float> {
@@ -94,42 +88,6 @@ __device__ __forceinline__ void stage_image(bf16_t* img, const bf16_t* g, int64_
     if (r < S) v = *(const bf16x8*)(g + r * g_ld + c * 8);
     *(bf16x8*)(img + r * IMG_LD + c * 8) = v;
   }
-}
-
-struct BiasCtx {
-  int seq, h, S, H;
-  const uint8_t* key_mask;
-  const uint8_t* key_pad;
-  const float* dense;
-  const float* attn_bias;
-  const int32_t* sp;
-  const void* table;
-  const void* virt;
-};
-
-template <typename T>
-__device__ __forceinline__ float key_only_bias(const BiasCtx& b, int key) {
-  if (key >= b.S) return -INFINITY;
-  if (b.key_mask && !b.key_mask[(int64_t)b.seq * b.S + key]) return -INFINITY;
-  if (b.key_pad && b.key_pad[(int64_t)b.seq * b.S + key]) return -INFINITY;
-  return 0.f;
-}
-
-// additive bias of score (q, key), both < S
-template <typename T, bool STRUCT>
-__device__ __forceinline__ float pair_bias(const BiasCtx& b, int q, int key) {
-  float v = 0.f;
-  if (b.dense) v += b.dense[(((int64_t)b.seq * b.H + b.h) * b.S + q) * b.S + key];
-  if constexpr (STRUCT) {
-    v += 2.0f * b.attn_bias[((int64_t)b.seq * b.S + q) * b.S + key];  // graphormer_layers.py:93 and :108
-    if (q >= 1 && key >= 1) {
-      const int idx = b.sp[((int64_t)b.seq * (b.S - 1) + (q - 1)) * (b.S - 1) + (key - 1)];
-      v += to_f32(((const T*)b.table)[(int64_t)idx * b.H + b.h]);
-    } else {
-      v += to_f32(((const T*)b.virt)[b.h]);  // row 0 (graph token as query) or column 0 (as key)
-    }
-  }
-  return v;
 }
 
 template <typename T>
@@ -605,6 +563,7 @@ static int dispatch(hipStream_t st, const AttnParams& p) {
   const mdt_attn_fwd_args& a = p.f;
   const bool st_bias = a.attn_bias != nullptr;
   if (a.dtype == MDT_BF16) {
+    if (a.hd == 64 && !BWD && getenv("MDT_ATTN_V1") == nullptr) return attention_v2_dispatch(st, p, false);   // fwd: register-resident P
     if (a.hd == 64) return st_bias ? dispatch_nt<bf16_t, 64, true, BWD>(st, p) : dispatch_nt<bf16_t, 64, false, BWD>(st, p);
     set_error("attention(bf16): head_dim %d unsupported (64 only)", a.hd);
     return MDT_ERR_UNSUPPORTED;

@@ -1,0 +1,53 @@
+// Shared pieces of the two attention kernel families (attention.hip, attention_v2.hip).
+#pragma once
+#include "common.hpp"
+
+namespace mdt {
+
+struct AttnParams {
+  mdt_attn_fwd_args f;
+  DropCfg drop;
+  const void* dout; int64_t ld_dout;
+  void* dqkv; int64_t ld_dqkv;
+  float* d_dense_bias; float* d_sp_table; float* d_virt;
+};
+
+struct BiasCtx {
+  int seq, h, S, H;
+  const uint8_t* key_mask;
+  const uint8_t* key_pad;
+  const float* dense;
+  const float* attn_bias;
+  const int32_t* sp;
+  const void* table;
+  const void* virt;
+};
+
+template <typename T>
+__device__ __forceinline__ float key_only_bias(const BiasCtx& b, int key) {
+  if (key >= b.S) return -INFINITY;
+  if (b.key_mask && !b.key_mask[(int64_t)b.seq * b.S + key]) return -INFINITY;
+  if (b.key_pad && b.key_pad[(int64_t)b.seq * b.S + key]) return -INFINITY;
+  return 0.f;
+}
+
+// additive bias of score (q, key), both < S
+template <typename T, bool STRUCT>
+__device__ __forceinline__ float pair_bias(const BiasCtx& b, int q, int key) {
+  float v = 0.f;
+  if (b.dense) v += b.dense[(((int64_t)b.seq * b.H + b.h) * b.S + q) * b.S + key];
+  if constexpr (STRUCT) {
+    v += 2.0f * b.attn_bias[((int64_t)b.seq * b.S + q) * b.S + key];  // graphormer_layers.py:93 and :108
+    if (q >= 1 && key >= 1) {
+      const int idx = b.sp[((int64_t)b.seq * (b.S - 1) + (q - 1)) * (b.S - 1) + (key - 1)];
+      v += to_f32(((const T*)b.table)[(int64_t)idx * b.H + b.h]);
+    } else {
+      v += to_f32(((const T*)b.virt)[b.h]);  // row 0 (graph token as query) or column 0 (as key)
+    }
+  }
+  return v;
+}
+
+int attention_v2_dispatch(hipStream_t st, const AttnParams& p, bool bwd);
+
+}  // namespace mdt

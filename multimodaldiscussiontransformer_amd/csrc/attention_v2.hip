@@ -1,0 +1,403 @@
+// bf16 attention, second generation: probabilities never leave the register file.
+//
+// Scores are computed TRANSPOSED — keys on the MFMA rows (registers), queries on the lanes —
+// so the 16x16 fp32 accumulator tiles of S^T are already laid out as the B operand of the next
+// product (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand"):
+//   forward   S^T = K Q^T          ->  P^T (softmax down the registers + 2 shuffles)
+//             O^T = V^T P^T            (V^T fetched from the row-major LDS image with ds_read_b64_tr_b16)
+//   backward  pass A (queries on lanes):  dP^T = V dO^T, dS^T = P^T (dP^T - delta),  dQ^T = K^T dS^T
+//             pass B (keys on lanes):     S = Q K^T, dP = dO V^T, dV^T = dO^T P, dK^T = Q^T dS
+// A pair of 16-key (or 16-query) accumulator tiles forms one K = 32 operand: element j of lane
+// (g, c) is row 4g + j of tile t0 (j < 4) or of tile t0+1 (j >= 4); the transposed-read operand
+// is addressed with the same row permutation, so no data is ever shuffled between lanes.
+// Compared with attention.hip this removes the P / dS round trip through LDS (28-52 two-byte
+// ds_writes + wave fences per tile), halves the LDS footprint (4 workgroups per CU at S = 104)
+// and reduces the softmax reductions from four shuffles to two.
+// Same C ABI, same masks / structural bias / dropout semantics; attention.hip keeps the fp32
+// parity path and remains selectable for bf16 with MDT_ATTN_V1=1.
+#include "attention_common.hpp"
+
+namespace mdt {
+
+constexpr int V2_LD = 72;  // LDS image row stride in elements (144 B)
+
+template <int HD>
+__device__ __forceinline__ void v2_stage(bf16_t* img, const bf16_t* g, int64_t g_ld, int S, int rows_pad, int tid) {
+  constexpr int CH = HD / 8;
+  for (int e = tid; e < rows_pad * CH; e += 256) {
+    const int r = e / CH, c = e - r * CH;
+    bf16x8 v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < S) v = *(const bf16x8*)(g + r * g_ld + c * 8);
+    *(bf16x8*)(img + r * V2_LD + c * 8) = v;
+  }
+}
+
+// A / B fragment with k along the contiguous axis: element(rc, k) = p[rc*ld + k]
+__device__ __forceinline__ bf16x8 v2_frag_lds(const bf16_t* img, int rc0, int k0, int lane) {
+  const bf16_t* a = img + (rc0 + (lane & 15)) * V2_LD + k0 + 8 * (lane >> 4);
+  return *(const __attribute__((address_space(3))) bf16x8*)LDS_PTR(a);
+}
+__device__ __forceinline__ bf16x8 v2_frag_glb(const bf16_t* p, int64_t ld, int rows, int rc0, int k0, int lane) {
+  int rc = rc0 + (lane & 15);
+  if (rc > rows - 1) rc = rows - 1;
+  return *(const bf16x8*)(p + rc * ld + k0 + 8 * (lane >> 4));
+}
+// A operand X^T[d][k] for a K = 32 step whose k index runs over rows {t0*16 + 4g + j} (j < 4)
+// and {(t0+1)*16 + 4g + j - 4} of the row-major image X[row][d]
+__device__ __forceinline__ bf16x8 v2_frag_tr(const bf16_t* img, int t0, int d0, int lane) {
+  const int g = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
+  const bf16_t* a = img + (t0 * 16 + 4 * g + q4) * V2_LD + d0 + pp * 4;
+  const bf16x4 lo = lds_read_tr16(a);
+  const bf16x4 hi = lds_read_tr16(a + 16 * V2_LD);
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// B operand from two accumulator tiles (rows = k index)
+__device__ __forceinline__ bf16x8 v2_pack(const f32x4& lo, const f32x4& hi) {
+  return bf16x8{(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
+                (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+}
+__device__ __forceinline__ float col_max(float v) {  // over the 4 lanes that share a column
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float col_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// ---------------------------------------------------------------------------- forward
+template <int HD, int NT, bool STRUCT, bool DROP>
+__global__ __launch_bounds__(256, (NT <= 7 ? 3 : 2)) void attn_fwd_v2_kernel(AttnParams P) {
+  constexpr int ND = HD / 16, NP = (NT + 1) / 2, S_PAD = NP * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const mdt_attn_fwd_args& a = P.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, seq = blockIdx.y;
+  const int S = a.S, D = a.H * HD;
+  const int64_t row0 = (int64_t)seq * a.seq_stride;
+  const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * a.ld_qkv + h * HD;
+  const int64_t tld = a.pos_stride * a.ld_qkv;
+  bf16_t* imgK = (bf16_t*)smem;
+  bf16_t* imgV = imgK + S_PAD * V2_LD;
+  float* s_kb = (float*)(imgV + S_PAD * V2_LD);   // key-only bias (0 / -inf), [S_PAD]
+  BiasCtx bc{seq, h, S, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
+  v2_stage<HD>(imgK, qkv + D, tld, S, S_PAD, tid);
+  v2_stage<HD>(imgV, qkv + 2 * D, tld, S, S_PAD, tid);
+  for (int i = tid; i < S_PAD; i += 256) s_kb[i] = key_only_bias<bf16_t>(bc, i);
+  __syncthreads();
+  const uint32_t drop_base = (uint32_t)((seq * a.H + h) * S) * (uint32_t)S;
+  const int g = lane >> 4, c = lane & 15;
+  const int n_qt = (S + 15) >> 4;
+  for (int qt = wave; qt < n_qt; qt += 4) {
+    const int q0 = qt * 16;
+    const int q = q0 + c;
+    const int qc = q < S ? q : S - 1;
+    bf16x8 fq[HD / 32];
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) fq[ks] = v2_frag_glb(qkv, tld, S, q0, ks * 32, lane);
+    f32x4 sc[2 * NP];
+#pragma unroll
+    for (int t = 0; t < 2 * NP; ++t) sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int ks = 0; ks < HD / 32; ++ks) sc[t] = mfma_bf16(v2_frag_lds(imgK, t * 16, ks * 32, lane), fq[ks], sc[t]);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * 16 + 4 * g + r;
+        float v = sc[t][r] * a.scale + s_kb[key];
+        if ((a.dense_bias || STRUCT) && key < S) v += pair_bias<bf16_t, STRUCT>(bc, qc, key);
+        sc[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = col_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = (sc[t][r] == -INFINITY) ? 0.f : __expf(sc[t][r] - mx);
+        sc[t][r] = e;
+        sum += e;
+      }
+    sum = col_sum(sum);
+    if (g == 0 && q < S) a.lse[((int64_t)seq * a.H + h) * S + q] = (sum > 0.f) ? mx + __logf(sum) : -INFINITY;
+    const float inv = (sum > 0.f) ? 1.0f / sum : 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pv = sc[t][r] * inv;
+        if constexpr (DROP) pv *= drop_scale(P.drop, (uint64_t)(drop_base + (uint32_t)(q * S + t * 16 + 4 * g + r)));
+        sc[t][r] = pv;
+      }
+    f32x4 o[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi) {
+      const bf16x8 fp = v2_pack(sc[2 * pi], sc[2 * pi + 1]);
+#pragma unroll
+      for (int d = 0; d < ND; ++d) o[d] = mfma_bf16(v2_frag_tr(imgV, 2 * pi, d * 16, lane), fp, o[d]);
+    }
+    if (q < S) {
+      bf16_t* orow = (bf16_t*)a.out + (row0 + (int64_t)q * a.pos_stride) * a.ld_out + h * HD + 4 * g;
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+        *(bf16x4*)(orow + d * 16) = bf16x4{(bf16_t)o[d][0], (bf16_t)o[d][1], (bf16_t)o[d][2], (bf16_t)o[d][3]};
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- backward
+// Measured SLOWER than attention.hip's backward on gfx950 / ROCm 7.2 (two live accumulator sets
+// of NT tiles + packed operands push it to 1 wave per SIMD and, from NT = 9, into scratch):
+// BERT S=104 2.36 vs 1.50 ms, ViT S=201 2.24 vs 1.74 ms (profiles/round1_attention_v2.txt).  Kept
+// for reference, built only with -DMDT_ATTN_V2_BWD; the default backward stays attention.hip.
+#ifdef MDT_ATTN_V2_BWD
+template <int HD, int NT, bool STRUCT, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
+  constexpr int ND = HD / 16, NP = (NT + 1) / 2, S_PAD = NP * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const mdt_attn_fwd_args& a = P.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, seq = blockIdx.y;
+  const int S = a.S, D = a.H * HD;
+  const int64_t row0 = (int64_t)seq * a.seq_stride;
+  const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * a.ld_qkv + h * HD;
+  const bf16_t* dout = (const bf16_t*)P.dout + row0 * P.ld_dout + h * HD;
+  bf16_t* dqkv = (bf16_t*)P.dqkv + row0 * P.ld_dqkv + h * HD;
+  const int64_t tld = a.pos_stride * a.ld_qkv, dld = a.pos_stride * P.ld_dout, gld = a.pos_stride * P.ld_dqkv;
+  bf16_t* img0 = (bf16_t*)smem;
+  bf16_t* img1 = img0 + S_PAD * V2_LD;
+  float* s_kb = (float*)(img1 + S_PAD * V2_LD);
+  float* s_lse = s_kb + S_PAD;
+  float* s_delta = s_lse + S_PAD;
+  float* s_hist = s_delta + S_PAD;
+  const int nhist = STRUCT ? ((a.num_spatial + 1 + 3) & ~3) : 0;
+  BiasCtx bc{seq, h, S, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
+  v2_stage<HD>(img0, qkv + D, tld, S, S_PAD, tid);      // K
+  v2_stage<HD>(img1, qkv + 2 * D, tld, S, S_PAD, tid);  // V
+  for (int i = tid; i < S_PAD; i += 256) {
+    s_kb[i] = key_only_bias<bf16_t>(bc, i);
+    s_lse[i] = (i < S) ? a.lse[((int64_t)seq * a.H + h) * S + i] : -INFINITY;
+    s_delta[i] = 0.f;
+  }
+  for (int i = tid; i < nhist; i += 256) s_hist[i] = 0.f;
+  __syncthreads();
+  const uint32_t drop_base = (uint32_t)((seq * a.H + h) * S) * (uint32_t)S;
+  const int g = lane >> 4, c = lane & 15;
+  const int n_t = (S + 15) >> 4;
+
+  // ------------------------------------------------------------------ pass A: queries on lanes
+  for (int qt = wave; qt < n_t; qt += 4) {
+    const int q0 = qt * 16;
+    const int q = q0 + c;
+    const bool qok = q < S;
+    const int qc = qok ? q : S - 1;
+    bf16x8 fq[HD / 32], fo[HD / 32];
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      fq[ks] = v2_frag_glb(qkv, tld, S, q0, ks * 32, lane);
+      fo[ks] = v2_frag_glb(dout, dld, S, q0, ks * 32, lane);
+    }
+    f32x4 sc[2 * NP], dp[2 * NP];
+#pragma unroll
+    for (int t = 0; t < 2 * NP; ++t) { sc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int ks = 0; ks < HD / 32; ++ks) {
+        sc[t] = mfma_bf16(v2_frag_lds(img0, t * 16, ks * 32, lane), fq[ks], sc[t]);
+        dp[t] = mfma_bf16(v2_frag_lds(img1, t * 16, ks * 32, lane), fo[ks], dp[t]);
+      }
+    const float l = s_lse[qc];
+    float del = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * 16 + 4 * g + r;
+        float v = sc[t][r] * a.scale + s_kb[key];
+        if ((a.dense_bias || STRUCT) && key < S) v += pair_bias<bf16_t, STRUCT>(bc, qc, key);
+        const float p = (v == -INFINITY || l == -INFINITY || !qok) ? 0.f : __expf(v - l);
+        sc[t][r] = p;
+        if constexpr (DROP) dp[t][r] *= drop_scale(P.drop, (uint64_t)(drop_base + (uint32_t)(q * S + key)));
+        del += p * dp[t][r];
+      }
+    del = col_sum(del);
+    if (g == 0 && qok) s_delta[q] = del;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ds = sc[t][r] * (dp[t][r] - del);
+        sc[t][r] = ds;
+        const int key = t * 16 + 4 * g + r;
+        if (qok && key < S) {
+          if (P.d_dense_bias) P.d_dense_bias[(((int64_t)seq * a.H + h) * S + q) * S + key] = ds;
+          if constexpr (STRUCT) {
+            if (P.d_sp_table && ds != 0.f) {
+              if (q >= 1 && key >= 1) {
+                const int idx = a.spatial_pos[((int64_t)seq * (S - 1) + (q - 1)) * (S - 1) + (key - 1)];
+                if (idx != 0) atomicAdd(s_hist + idx, ds);
+              } else {
+                atomicAdd(s_hist + a.num_spatial, ds);
+              }
+            }
+          }
+        }
+      }
+    f32x4 dq[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi) {
+      const bf16x8 fs = v2_pack(sc[2 * pi], sc[2 * pi + 1]);
+#pragma unroll
+      for (int d = 0; d < ND; ++d) dq[d] = mfma_bf16(v2_frag_tr(img0, 2 * pi, d * 16, lane), fs, dq[d]);
+    }
+    if (qok) {
+      bf16_t* orow = dqkv + (int64_t)q * gld + 4 * g;
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+        *(bf16x4*)(orow + d * 16) = bf16x4{(bf16_t)(dq[d][0] * a.scale), (bf16_t)(dq[d][1] * a.scale),
+                                           (bf16_t)(dq[d][2] * a.scale), (bf16_t)(dq[d][3] * a.scale)};
+    }
+  }
+  __syncthreads();   // delta complete; K / V images are free
+  v2_stage<HD>(img0, qkv, tld, S, S_PAD, tid);    // Q
+  v2_stage<HD>(img1, dout, dld, S, S_PAD, tid);   // dO
+  if constexpr (STRUCT) {
+    if (P.d_sp_table) {
+      for (int i = tid; i <= a.num_spatial; i += 256) {
+        const float v = s_hist[i];
+        if (v != 0.f) {
+          if (i < a.num_spatial) atomicAdd(P.d_sp_table + (int64_t)i * a.H + h, v);
+          else if (P.d_virt) atomicAdd(P.d_virt + h, v);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ------------------------------------------------------------------ pass B: keys on lanes
+  for (int kt = wave; kt < n_t; kt += 4) {
+    const int key0 = kt * 16;
+    const int key = key0 + c;
+    const bool kok = key < S;
+    const float kb = s_kb[key];
+    bf16x8 fk[HD / 32], fv[HD / 32];
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      fk[ks] = v2_frag_glb(qkv + D, tld, S, key0, ks * 32, lane);
+      fv[ks] = v2_frag_glb(qkv + 2 * D, tld, S, key0, ks * 32, lane);
+    }
+    f32x4 sc[2 * NP], dp[2 * NP];
+#pragma unroll
+    for (int t = 0; t < 2 * NP; ++t) { sc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int ks = 0; ks < HD / 32; ++ks) {
+        sc[t] = mfma_bf16(v2_frag_lds(img0, t * 16, ks * 32, lane), fk[ks], sc[t]);   // S[q][key]
+        dp[t] = mfma_bf16(v2_frag_lds(img1, t * 16, ks * 32, lane), fv[ks], dp[t]);   // dP[q][key] = dO V^T
+      }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = t * 16 + 4 * g + r;
+        const bool qok = q < S;
+        const int qc = qok ? q : S - 1;
+        float v = sc[t][r] * a.scale + kb;
+        if ((a.dense_bias || STRUCT) && kok) v += pair_bias<bf16_t, STRUCT>(bc, qc, key);
+        const float l = s_lse[q];
+        const float p = (v == -INFINITY || l == -INFINITY || !qok || !kok) ? 0.f : __expf(v - l);
+        float ds = dp[t][r];
+        float pd = p;
+        if constexpr (DROP) {
+          const float m = drop_scale(P.drop, (uint64_t)(drop_base + (uint32_t)(qc * S + key)));
+          ds *= m;
+          pd *= m;
+        }
+        sc[t][r] = pd;                          // (dropped) P, operand of dV
+        dp[t][r] = p * (ds - s_delta[q]);       // dS
+      }
+    f32x4 dv[ND], dk[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) { dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi) {
+      const bf16x8 fp = v2_pack(sc[2 * pi], sc[2 * pi + 1]);
+      const bf16x8 fs = v2_pack(dp[2 * pi], dp[2 * pi + 1]);
+#pragma unroll
+      for (int d = 0; d < ND; ++d) {
+        dv[d] = mfma_bf16(v2_frag_tr(img1, 2 * pi, d * 16, lane), fp, dv[d]);   // dO^T P
+        dk[d] = mfma_bf16(v2_frag_tr(img0, 2 * pi, d * 16, lane), fs, dk[d]);   // Q^T dS
+      }
+    }
+    if (kok) {
+      bf16_t* krow = dqkv + (int64_t)key * gld + D + 4 * g;
+      bf16_t* vrow = dqkv + (int64_t)key * gld + 2 * D + 4 * g;
+#pragma unroll
+      for (int d = 0; d < ND; ++d) {
+        *(bf16x4*)(krow + d * 16) = bf16x4{(bf16_t)(dk[d][0] * a.scale), (bf16_t)(dk[d][1] * a.scale),
+                                           (bf16_t)(dk[d][2] * a.scale), (bf16_t)(dk[d][3] * a.scale)};
+        *(bf16x4*)(vrow + d * 16) = bf16x4{(bf16_t)dv[d][0], (bf16_t)dv[d][1], (bf16_t)dv[d][2], (bf16_t)dv[d][3]};
+      }
+    }
+  }
+}
+
+#endif  // MDT_ATTN_V2_BWD
+
+template <int NT, bool STRUCT, bool DROP, bool BWD>
+static int launch_v2(hipStream_t st, const AttnParams& p) {
+  constexpr int S_PAD = ((NT + 1) / 2) * 32;
+  const int nhist = (STRUCT && BWD) ? ((p.f.num_spatial + 1 + 3) & ~3) : 0;
+  const size_t lds = (size_t)2 * S_PAD * V2_LD * 2 + (size_t)(BWD ? 3 : 1) * S_PAD * 4 + (size_t)nhist * 4;
+#ifdef MDT_ATTN_V2_BWD
+  const void* kern = BWD ? (const void*)attn_bwd_v2_kernel<64, NT, STRUCT, DROP> : (const void*)attn_fwd_v2_kernel<64, NT, STRUCT, DROP>;
+#else
+  if (BWD) { set_error("attention_v2: backward not built (MDT_ATTN_V2_BWD)"); return MDT_ERR_UNSUPPORTED; }
+  const void* kern = (const void*)attn_fwd_v2_kernel<64, NT, STRUCT, DROP>;
+#endif
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("attention_v2: cannot reserve %zu bytes of LDS", lds);
+      return MDT_ERR_LAUNCH;
+    }
+  }
+#ifdef MDT_ATTN_V2_BWD
+  if (BWD) hipLaunchKernelGGL((attn_bwd_v2_kernel<64, NT, STRUCT, DROP>), dim3(p.f.H, p.f.nseq), 256, lds, st, p);
+  else
+#endif
+    hipLaunchKernelGGL((attn_fwd_v2_kernel<64, NT, STRUCT, DROP>), dim3(p.f.H, p.f.nseq), 256, lds, st, p);
+  return check_launch(BWD ? "attention_bwd_v2" : "attention_fwd_v2");
+}
+
+template <bool STRUCT, bool DROP, bool BWD>
+static int dispatch_v2_nt(hipStream_t st, const AttnParams& p) {
+  const int nt = (p.f.S + 15) / 16;
+#define V2_CASE(N_) if (nt <= N_) return launch_v2<N_, STRUCT, DROP, BWD>(st, p);
+  V2_CASE(2) V2_CASE(5) V2_CASE(7) V2_CASE(9) V2_CASE(13) V2_CASE(16)
+#undef V2_CASE
+  set_error("attention_v2: S=%d exceeds 256", p.f.S);
+  return MDT_ERR_UNSUPPORTED;
+}
+
+int attention_v2_dispatch(hipStream_t st, const AttnParams& p, bool bwd) {
+  const bool s = p.f.attn_bias != nullptr, d = p.f.drop_p > 0.f;
+#define V2_GO(S_, D_) return bwd ? dispatch_v2_nt<S_, D_, true>(st, p) : dispatch_v2_nt<S_, D_, false>(st, p);
+  if (s && d) V2_GO(true, true)
+  if (s) V2_GO(true, false)
+  if (d) V2_GO(false, true)
+  V2_GO(false, false)
+#undef V2_GO
+}
+
+}  // namespace mdt
