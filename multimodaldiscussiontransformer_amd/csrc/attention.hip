@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams P) {
         for (int t = 0; t < NT; ++t) {
           sc[t] = MM<T>::mma(fq, frag_kc<T, BF>(srcK, t * 16, k0, lane), sc[t]);
           dp[t] = MM<T>::mma(fo, frag_kc<T, BF>(srcV, t * 16, k0, lane), dp[t]);
+          if (t & 1) __builtin_amdgcn_sched_barrier(0);   // bound operand prefetch depth (registers -> occupancy)
         }
       }
       float del[4] = {0.f, 0.f, 0.f, 0.f};
@@ -415,6 +416,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams P) {
         for (int t = 0; t < NT; ++t) {
           sc[t] = MM<T>::mma(fk, frag_kc<T, BF>(srcQ, t * 16, k0, lane), sc[t]);
           dp[t] = MM<T>::mma(fv, frag_kc<T, BF>(srcDO, t * 16, k0, lane), dp[t]);
+          if (t & 1) __builtin_amdgcn_sched_barrier(0);
         }
       }
       // rows = keys key0 + (lane>>4)*4 + r, cols = queries t*16 + (lane&15)
@@ -563,7 +565,8 @@ static int dispatch(hipStream_t st, const AttnParams& p) {
   const mdt_attn_fwd_args& a = p.f;
   const bool st_bias = a.attn_bias != nullptr;
   if (a.dtype == MDT_BF16) {
-    if (a.hd == 64 && !BWD && getenv("MDT_ATTN_V1") == nullptr) return attention_v2_dispatch(st, p, false);   // fwd: register-resident P
+    if (a.hd == 64 && getenv("MDT_ATTN_V1") == nullptr && (!BWD || getenv("MDT_ATTN_V2_BWD") != nullptr))
+      return attention_v2_dispatch(st, p, BWD);   // fwd: register-resident P
     if (a.hd == 64) return st_bias ? dispatch_nt<bf16_t, 64, true, BWD>(st, p) : dispatch_nt<bf16_t, 64, false, BWD>(st, p);
     set_error("attention(bf16): head_dim %d unsupported (64 only)", a.hd);
     return MDT_ERR_UNSUPPORTED;

@@ -15,6 +15,7 @@
 // and reduces the softmax reductions from four shuffles to two.
 // Same C ABI, same masks / structural bias / dropout semantics; attention.hip keeps the fp32
 // parity path and remains selectable for bf16 with MDT_ATTN_V1=1.
+#define MDT_ATTN_V2_BWD 1   // built; selected at run time with MDT_ATTN_V2_BWD=1 (default backward: attention.hip)
 #include "attention_common.hpp"
 
 namespace mdt {
@@ -67,7 +68,7 @@ __device__ __forceinline__ float col_sum(float v) {
 
 // ---------------------------------------------------------------------------- forward
 template <int HD, int NT, bool STRUCT, bool DROP>
-__global__ __launch_bounds__(256, (NT <= 7 ? 3 : 2)) void attn_fwd_v2_kernel(AttnParams P) {
+__global__ __launch_bounds__(256) void attn_fwd_v2_kernel(AttnParams P) {
   constexpr int ND = HD / 16, NP = (NT + 1) / 2, S_PAD = NP * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mdt_attn_fwd_args& a = P.f;
@@ -101,7 +102,10 @@ __global__ __launch_bounds__(256, (NT <= 7 ? 3 : 2)) void attn_fwd_v2_kernel(Att
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int ks = 0; ks < HD / 32; ++ks) sc[t] = mfma_bf16(v2_frag_lds(imgK, t * 16, ks * 32, lane), fq[ks], sc[t]);
+      for (int ks = 0; ks < HD / 32; ++ks) {
+        sc[t] = mfma_bf16(v2_frag_lds(imgK, t * 16, ks * 32, lane), fq[ks], sc[t]);
+        if (ks == HD / 32 - 1 && (t & 1)) __builtin_amdgcn_sched_barrier(0);   // bound operand prefetch depth (registers)
+      }
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -142,6 +146,7 @@ __global__ __launch_bounds__(256, (NT <= 7 ? 3 : 2)) void attn_fwd_v2_kernel(Att
       const bf16x8 fp = v2_pack(sc[2 * pi], sc[2 * pi + 1]);
 #pragma unroll
       for (int d = 0; d < ND; ++d) o[d] = mfma_bf16(v2_frag_tr(imgV, 2 * pi, d * 16, lane), fp, o[d]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (q < S) {
       bf16_t* orow = (bf16_t*)a.out + (row0 + (int64_t)q * a.pos_stride) * a.ld_out + h * HD + 4 * g;
@@ -213,6 +218,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
       for (int ks = 0; ks < HD / 32; ++ks) {
         sc[t] = mfma_bf16(v2_frag_lds(img0, t * 16, ks * 32, lane), fq[ks], sc[t]);
         dp[t] = mfma_bf16(v2_frag_lds(img1, t * 16, ks * 32, lane), fo[ks], dp[t]);
+        if (ks == HD / 32 - 1) __builtin_amdgcn_sched_barrier(0);
       }
     const float l = s_lse[qc];
     float del = 0.f;
@@ -259,6 +265,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
       const bf16x8 fs = v2_pack(sc[2 * pi], sc[2 * pi + 1]);
 #pragma unroll
       for (int d = 0; d < ND; ++d) dq[d] = mfma_bf16(v2_frag_tr(img0, 2 * pi, d * 16, lane), fs, dq[d]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (qok) {
       bf16_t* orow = dqkv + (int64_t)q * gld + 4 * g;
@@ -304,6 +311,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
       for (int ks = 0; ks < HD / 32; ++ks) {
         sc[t] = mfma_bf16(v2_frag_lds(img0, t * 16, ks * 32, lane), fk[ks], sc[t]);   // S[q][key]
         dp[t] = mfma_bf16(v2_frag_lds(img1, t * 16, ks * 32, lane), fv[ks], dp[t]);   // dP[q][key] = dO V^T
+        if (ks == HD / 32 - 1) __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -338,6 +346,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
         dv[d] = mfma_bf16(v2_frag_tr(img1, 2 * pi, d * 16, lane), fp, dv[d]);   // dO^T P
         dk[d] = mfma_bf16(v2_frag_tr(img0, 2 * pi, d * 16, lane), fs, dk[d]);   // Q^T dS
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (kok) {
       bf16_t* krow = dqkv + (int64_t)key * gld + D + 4 * g;
