@@ -43,6 +43,8 @@ enum {
   MDT_EPI_DGELU = 8,     /* * gelu'(aux[m, n]) (backward of MDT_EPI_GELU) */
   MDT_EPI_ACCUM = 16,    /* C += result (plain read-modify-write, fp32 or T) */
   MDT_EPI_ATOMIC = 32,   /* C (fp32) += result with float atomics (split-K weight gradients) */
+  MDT_EPI_COLSUM = 128,  /* colsum[n] += sum_m C[m, n] (fp32 atomics) — the bias gradient of the layer whose
+                            output gradient this GEMM produces, fused instead of a separate pass */
   MDT_EPI_DROPOUT = 64   /* inverted dropout on the value after bias / GELU and before the residual add
                             (with MDT_EPI_DGELU: on the incoming gradient, before the GELU' factor);
                             element (m, n) of site `drop_seed` uses counter m*N + n */
@@ -66,7 +68,7 @@ int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int trans_b,
              const void* A, int64_t lda, const void* B, int64_t ldb,
              void* C, int64_t ldc, int epilogue, float alpha,
              const void* bias, const void* residual, int64_t ldr,
-             void* aux, int64_t ldaux, int split_k, float drop_p, uint64_t drop_seed);
+             void* aux, int64_t ldaux, int split_k, float drop_p, uint64_t drop_seed, float* colsum);
 
 /* Inverted dropout as a stand-alone op: y[m, n] = x[m, n] * keep(seed, m*D + n) / (1 - p).  The mask is
  * a pure function of (seed, counter), so calling it on the gradient with the same seed is the backward
@@ -91,10 +93,14 @@ int mdt_colsum(void* stream, int dtype, int64_t M, int64_t N, const void* X, int
 int mdt_layernorm_fwd(void* stream, int dtype, int64_t rows, int D, const void* x, int64_t ldx,
                       const void* gamma, const void* beta, float eps,
                       void* y, int64_t ldy, float* mean, float* rstd);
-/* dx = LN'(dy) (+ add[m,:] if add != NULL);  dgamma/dbeta fp32, atomically accumulated. */
+/* dx = LN'(dy) (+ add[m,:] if add != NULL);  dgamma/dbeta fp32, atomically accumulated.
+ * Optional fused tail for the layer that FEEDS this LayerNorm through a hidden dropout + residual:
+ *   dxd (may be NULL) = dx * keep(drop_seed, m*D + n) / (1 - drop_p)   — gradient of the dense output,
+ *   colsum (may be NULL, fp32[D]) += column sums of dxd (of dx when dxd is NULL) — that layer's bias gradient. */
 int mdt_layernorm_bwd(void* stream, int dtype, int64_t rows, int D, const void* dy, int64_t lddy,
                       const void* x, int64_t ldx, const void* gamma, const float* mean, const float* rstd,
-                      const void* add, int64_t ldadd, void* dx, int64_t lddx, float* dgamma, float* dbeta);
+                      const void* add, int64_t ldadd, void* dx, int64_t lddx, float* dgamma, float* dbeta,
+                      void* dxd, int64_t lddxd, float drop_p, uint64_t drop_seed, float* colsum);
 
 /* ------------------------------------------------------------------ attention
  * Self-attention over `nseq` independent sequences of `S` tokens, `H` heads of `hd`,

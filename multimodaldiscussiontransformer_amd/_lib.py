@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmdt_hip.so")
 
 MDT_F32, MDT_BF16 = 0, 1
-EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_ACCUM, EPI_ATOMIC, EPI_DROPOUT = 1, 2, 4, 8, 16, 32, 64
+EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_ACCUM, EPI_ATOMIC, EPI_DROPOUT, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64, 128
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -42,12 +42,13 @@ _SIGS = {
     "mdt_abi_version": ([], _i),
     "mdt_last_error_string": ([], C.c_char_p),
     "mdt_gemm": ([_vp, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _f, _vp, _vp, _i64,
-                  _vp, _i64, _i, _f, C.c_uint64], _i),
+                  _vp, _i64, _i, _f, C.c_uint64, _vp], _i),
     "mdt_dropout": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _i64, _f, C.c_uint64], _i),
     "mdt_dropout_mask": ([_vp, _i64, _f, C.c_uint64, _vp], _i),
     "mdt_colsum": ([_vp, _i, _i64, _i64, _vp, _i64, _vp, _vp], _i),
     "mdt_layernorm_fwd": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _vp, _f, _vp, _i64, _vp, _vp], _i),
-    "mdt_layernorm_bwd": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp], _i),
+    "mdt_layernorm_bwd": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp,
+                           _vp, _i64, _f, C.c_uint64, _vp], _i),
     "mdt_attention_fwd": ([_vp, C.POINTER(AttnFwdArgs)], _i),
     "mdt_attention_bwd": ([_vp, C.POINTER(AttnBwdArgs)], _i),
     "mdt_graph_attn_bias": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),

@@ -29,6 +29,7 @@ struct GemmParams {
   int split_k; int64_t k_chunk;
   int tiles_m, tiles_n;
   DropCfg drop;
+  float* colsum;
 };
 
 // ------------------------------------------------------------------ shared epilogue
@@ -46,6 +47,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t row,
   if (p.epilogue & MDT_EPI_DROPOUT) v *= drop_scale(p.drop, (uint64_t)row * p.N + col);
   if (p.epilogue & MDT_EPI_DGELU) v *= gelu_erf_grad(to_f32(((const TIn*)p.aux)[row * p.ldaux + col]));
   if (p.epilogue & MDT_EPI_RESIDUAL) v += to_f32(((const TIn*)p.residual)[row * p.ldr + col]);
+  if (p.epilogue & MDT_EPI_COLSUM) atomicAdd(p.colsum + col, v);
   TOut* c = (TOut*)p.C + row * p.ldc + col;
   if constexpr (sizeof(TOut) == 4) {
     if (p.epilogue & MDT_EPI_ATOMIC) { atomicAdd((float*)c, v); return; }
@@ -212,6 +214,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[e] = (float)b[e];
   }
+  float cs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
 #pragma unroll 2
   for (int pass = 0; pass < 8; ++pass) {
     const int row = pass * 8 + (lane >> 3);
@@ -246,6 +251,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
     }
+    if (ep & MDT_EPI_COLSUM) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs[e] += v[e];
+    }
     if constexpr (sizeof(TOut) == 4) {
       float* c = (float*)p.C + gr * p.ldc + gc;
       if (ep & MDT_EPI_ACCUM) {
@@ -266,6 +275,16 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
       *(bf16x8*)c = o;
+    }
+  }
+  if (ep & MDT_EPI_COLSUM) {   // 8 row-lanes per column group -> one atomic per column per wave
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s_ = cs[e];
+      s_ += __shfl_xor(s_, 8, 64);
+      s_ += __shfl_xor(s_, 16, 64);
+      s_ += __shfl_xor(s_, 32, 64);
+      if (lane < 8) atomicAdd(p.colsum + gc + e, s_);
     }
   }
 }
@@ -712,7 +731,7 @@ using namespace mdt;
 extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int trans_b, int64_t M, int64_t N,
                         int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                         int epilogue, float alpha, const void* bias, const void* residual, int64_t ldr, void* aux,
-                        int64_t ldaux, int split_k, float drop_p, uint64_t drop_seed) {
+                        int64_t ldaux, int split_k, float drop_p, uint64_t drop_seed, float* colsum) {
   MDT_CHECK_ARG(dtype == MDT_F32 || dtype == MDT_BF16, "mdt_gemm: bad dtype %d", dtype);
   MDT_CHECK_ARG(out_dtype == MDT_F32 || out_dtype == MDT_BF16, "mdt_gemm: bad out_dtype %d", out_dtype);
   MDT_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "mdt_gemm: negative shape");
@@ -734,6 +753,8 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   p.epilogue = epilogue; p.alpha = alpha; p.bias = bias; p.residual = residual; p.ldr = ldr;
   p.aux = aux; p.ldaux = ldaux; p.split_k = split_k;
   p.drop = make_drop((epilogue & MDT_EPI_DROPOUT) ? drop_p : 0.f, drop_seed);
+  p.colsum = colsum;
+  MDT_CHECK_ARG(!(epilogue & MDT_EPI_COLSUM) || (colsum && split_k == 1), "mdt_gemm: MDT_EPI_COLSUM needs a colsum buffer and split_k == 1");
   // tile128 contract: bf16, output dims that are tiled along a contiguous axis must be
   // whole tiles, 16-B aligned rows.
   bool fast = dtype == MDT_BF16 && K > 0;

@@ -80,21 +80,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
                                                             const float* __restrict__ rstd, const T* __restrict__ add,
                                                             int64_t ldadd, T* __restrict__ dx, int64_t lddx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int rows_per_wave) {
+                                                            int rows_per_wave, T* __restrict__ dxd, int64_t lddxd,
+                                                            DropCfg drop, float* __restrict__ colsum) {
   constexpr int VN = Vec<T>::N;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* red = (float*)smem_raw;  // [2][4 waves][NV*64*VN]
+  float* red = (float*)smem_raw;  // [3][4 waves][NV*64*VN]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
   const int64_t r1 = (r0 + rows_per_wave < rows) ? r0 + rows_per_wave : rows;
-  float pg[NV][VN], pb[NV][VN];
+  float pg[NV][VN], pb[NV][VN], pc[NV][VN];
   Vec<T> gv[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * VN;
     if (c < D) gv[i] = *(const Vec<T>*)(gamma + c);
 #pragma unroll
-    for (int j = 0; j < VN; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; }
+    for (int j = 0; j < VN; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; pc[i][j] = 0.f; }
   }
   for (int64_t row = r0; row < r1; ++row) {
     const float mu = mean[row], rs = rstd[row];
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * VN;
       if (c < D) {
-        Vec<T> o, a;
+        Vec<T> o, od, a;
         if (add) a = *(const Vec<T>*)(add + row * ldadd + c);
 #pragma unroll
         for (int j = 0; j < VN; ++j) {
@@ -131,12 +132,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
           float v = rs * (gy[i].get(j) * gv[i].get(j) - m1 - xh * m2);
           if (add) v += a.get(j);
           o.set(j, v);
+          if (dxd) {   // second output: the gradient of the dense layer behind a hidden dropout
+            v = o.get(j) * drop_scale(drop, (uint64_t)row * D + c + j);
+            od.set(j, v);
+            v = od.get(j);
+          } else {
+            v = o.get(j);
+          }
+          pc[i][j] += v;
         }
         *(Vec<T>*)(dx + row * lddx + c) = o;
+        if (dxd) *(Vec<T>*)(dxd + row * lddxd + c) = od;
       }
     }
   }
-  if (!dgamma && !dbeta) return;
+  if (!dgamma && !dbeta && !colsum) return;
   const int W = NV * 64 * VN;
 #pragma unroll
   for (int i = 0; i < NV; ++i)
@@ -145,6 +155,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
       const int c = (i * 64 + lane) * VN + j;
       red[wave * W + c] = pg[i][j];
       red[(4 + wave) * W + c] = pb[i][j];
+      red[(8 + wave) * W + c] = pc[i][j];
     }
   __syncthreads();
   for (int c = threadIdx.x; c < D; c += 256) {
@@ -152,6 +163,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
     const float b = red[4 * W + c] + red[5 * W + c] + red[6 * W + c] + red[7 * W + c];
     if (dgamma) atomicAdd(dgamma + c, g);
     if (dbeta) atomicAdd(dbeta + c, b);
+    if (colsum) atomicAdd(colsum + c, red[8 * W + c] + red[9 * W + c] + red[10 * W + c] + red[11 * W + c]);
   }
 }
 
@@ -180,7 +192,8 @@ static int ln_fwd_dispatch(hipStream_t st, int64_t rows, int D, const void* x, i
 template <typename T>
 static int ln_bwd_dispatch(hipStream_t st, int64_t rows, int D, const void* dy, int64_t lddy, const void* x, int64_t ldx,
                            const void* gamma, const float* mean, const float* rstd, const void* add, int64_t ldadd,
-                           void* dx, int64_t lddx, float* dgamma, float* dbeta) {
+                           void* dx, int64_t lddx, float* dgamma, float* dbeta, void* dxd, int64_t lddxd, DropCfg drop,
+                           float* colsum) {
   constexpr int VN = Vec<T>::N;
   const int nv = (D + 64 * VN - 1) / (64 * VN);
   // ~2048 workgroups x 4 waves, at least 4 rows per wave so the column atomics stay few
@@ -188,9 +201,9 @@ static int ln_bwd_dispatch(hipStream_t st, int64_t rows, int D, const void* dy, 
   if (rpw < 4) rpw = 4;
   const unsigned grid = (unsigned)((rows + 4 * rpw - 1) / (4 * rpw));
 #define LN_BWD(NV_)                                                                                              \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV_>), grid, 256, (size_t)(8 * NV_ * 64 * VN * 4), st, rows, D,    \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV_>), grid, 256, (size_t)(12 * NV_ * 64 * VN * 4), st, rows, D,   \
                      (const T*)dy, lddy, (const T*)x, ldx, (const T*)gamma, mean, rstd, (const T*)add, ldadd,    \
-                     (T*)dx, lddx, dgamma, dbeta, rpw)
+                     (T*)dx, lddx, dgamma, dbeta, rpw, (T*)dxd, lddxd, drop, colsum)
   switch (nv) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;
@@ -231,13 +244,16 @@ extern "C" int mdt_layernorm_fwd(void* stream, int dtype, int64_t rows, int D, c
 
 extern "C" int mdt_layernorm_bwd(void* stream, int dtype, int64_t rows, int D, const void* dy, int64_t lddy,
                                  const void* x, int64_t ldx, const void* gamma, const float* mean, const float* rstd,
-                                 const void* add, int64_t ldadd, void* dx, int64_t lddx, float* dgamma, float* dbeta) {
+                                 const void* add, int64_t ldadd, void* dx, int64_t lddx, float* dgamma, float* dbeta,
+                                 void* dxd, int64_t lddxd, float drop_p, uint64_t drop_seed, float* colsum) {
   if (rows == 0) return MDT_OK;
+  MDT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "layernorm_bwd: dropout p=%f out of [0,1)", drop_p);
+  const DropCfg drop = make_drop(dxd ? drop_p : 0.f, drop_seed);
   MDT_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
   if (int e = ln_check(dtype, D, lddy, ldx, dy, x)) return e;
   if (int e = ln_check(dtype, D, lddx, add ? ldadd : lddx, dx, add ? add : dx)) return e;
   hipStream_t st = (hipStream_t)stream;
   return dtype == MDT_F32
-             ? ln_bwd_dispatch<float>(st, rows, D, dy, lddy, x, ldx, gamma, mean, rstd, add, ldadd, dx, lddx, dgamma, dbeta)
-             : ln_bwd_dispatch<bf16_t>(st, rows, D, dy, lddy, x, ldx, gamma, mean, rstd, add, ldadd, dx, lddx, dgamma, dbeta);
+             ? ln_bwd_dispatch<float>(st, rows, D, dy, lddy, x, ldx, gamma, mean, rstd, add, ldadd, dx, lddx, dgamma, dbeta, dxd, lddxd, drop, colsum)
+             : ln_bwd_dispatch<bf16_t>(st, rows, D, dy, lddy, x, ldx, gamma, mean, rstd, add, ldadd, dx, lddx, dgamma, dbeta, dxd, lddxd, drop, colsum);
 }

@@ -164,6 +164,15 @@ def _ln_bwd(tape, dy, x, w, b, mean, rstd, add=None):
     return ops.layernorm_bwd(dy, x, w.data, mean, rstd, add=add, dgamma=tape.pgrad(w), dbeta=tape.pgrad(b))
 
 
+def _ln_bwd_dense(tape, dy, x, w, b, mean, rstd, bias_param, p_drop, seed, add=None):
+    """LayerNorm backward + the fused tail for the dense layer that feeds it: returns (dx, dxd) where dxd is dx
+    through that layer's hidden-dropout mask, and accumulates the layer's bias gradient (column sums of dxd)."""
+    gb = tape.pgrad(bias_param) if bias_param is not None else None
+    return ops.layernorm_bwd(dy, x, w.data, mean, rstd, add=add, dgamma=tape.pgrad(w), dbeta=tape.pgrad(b),
+                             drop_p=p_drop, drop_seed=seed, colsum=None if gb is None else gb.view(-1),
+                             want_dropped=True)
+
+
 # ------------------------------------------------------------------------------------------
 # ops
 def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre_ln: bool, eps: float,
@@ -219,15 +228,15 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         o.grad = None
         if g is None:
             return
-        dy = _ln_bwd(tape, g, y, P.ln2_w, P.ln2_b, m2, r2)
-        dyd = hdrop(dy, s_f2)
-        wgrad(tape, dyd, h, P.fc2_w, P.fc2_b)
-        du = ops.gemm(dyd, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_DGELU, drop_p=p_act, drop_seed=s_act)
-        wgrad(tape, du, a, P.fc1_w, P.fc1_b)
+        dy, dyd = _ln_bwd_dense(tape, g, y, P.ln2_w, P.ln2_b, m2, r2, P.fc2_b, p_hidden, s_f2)
+        wgrad(tape, dyd, h, P.fc2_w, None)
+        gb1 = tape.pgrad(P.fc1_b)           # fc1 bias gradient = colsum(du): fused into the GEMM epilogue
+        du = ops.gemm(dyd, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_DGELU, drop_p=p_act, drop_seed=s_act,
+                      colsum=None if gb1 is None else gb1.view(-1))
+        wgrad(tape, du, a, P.fc1_w, None)
         da = ops.gemm(du, P.fc1_w.data, trans_b=True, residual=dy)
-        dt_ = _ln_bwd(tape, da, t, P.ln1_w, P.ln1_b, m1, r1)
-        dtd = hdrop(dt_, s_o)
-        wgrad(tape, dtd, ctx, P.o_w, P.o_b)
+        dt_, dtd = _ln_bwd_dense(tape, da, t, P.ln1_w, P.ln1_b, m1, r1, P.o_b, p_hidden, s_o)
+        wgrad(tape, dtd, ctx, P.o_w, None)
         dctx = ops.gemm(dtd, P.o_w.data, trans_b=True)
         dqkv = attn_bwd(dctx)
         wgrad(tape, dqkv, xd, P.qkv_w, P.qkv_b)
@@ -243,12 +252,13 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
             return
         gd = hdrop(g, s_f2)
         wgrad(tape, gd, f, P.fc2_w, P.fc2_b)
-        du = ops.gemm(gd, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_DGELU, drop_p=p_act, drop_seed=s_act)
-        wgrad(tape, du, n2, P.fc1_w, P.fc1_b)
+        gb1 = tape.pgrad(P.fc1_b)
+        du = ops.gemm(gd, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_DGELU, drop_p=p_act, drop_seed=s_act,
+                      colsum=None if gb1 is None else gb1.view(-1))
+        wgrad(tape, du, n2, P.fc1_w, None)
         dn2 = ops.gemm(du, P.fc1_w.data, trans_b=True)
-        dh = _ln_bwd(tape, dn2, hmid, P.ln2_w, P.ln2_b, m2, r2, add=g)
-        dhd = hdrop(dh, s_o)
-        wgrad(tape, dhd, ctx, P.o_w, P.o_b)
+        dh, dhd = _ln_bwd_dense(tape, dn2, hmid, P.ln2_w, P.ln2_b, m2, r2, P.o_b, p_hidden, s_o, add=g)
+        wgrad(tape, dhd, ctx, P.o_w, None)
         dctx = ops.gemm(dhd, P.o_w.data, trans_b=True)
         dqkv = attn_bwd(dctx)
         wgrad(tape, dqkv, n1, P.qkv_w, P.qkv_b)

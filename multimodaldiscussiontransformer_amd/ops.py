@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib as L
-from ._lib import (EPI_ACCUM, EPI_ATOMIC, EPI_BIAS, EPI_DGELU, EPI_DROPOUT, EPI_GELU, EPI_RESIDUAL, check, dt, lib,
+from ._lib import (EPI_ACCUM, EPI_ATOMIC, EPI_BIAS, EPI_COLSUM, EPI_DGELU, EPI_DROPOUT, EPI_GELU, EPI_RESIDUAL, check, dt, lib,
                    ptr, stream)
 
 __all__ = [
@@ -29,7 +29,7 @@ def _2d(t: torch.Tensor):
 
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out: Optional[torch.Tensor] = None,
          out_dtype=None, bias=None, residual=None, aux=None, epilogue=0, alpha=1.0, split_k=1, drop_p=0.0,
-         drop_seed=0) -> torch.Tensor:
+         drop_seed=0, colsum=None) -> torch.Tensor:
     """out[M,N] = epilogue(alpha * op(a) @ op(b)); b is [N,K] unless trans_b (then [K,N])."""
     lda, ldb = _2d(a), _2d(b)
     M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
@@ -50,10 +50,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
         assert aux.dtype == a.dtype and aux.shape == (M, N)
     if drop_p > 0.0:
         epilogue |= EPI_DROPOUT
+    if colsum is not None:
+        epilogue |= EPI_COLSUM
+        assert colsum.dtype == torch.float32 and colsum.numel() == N
     check(lib.mdt_gemm(stream(), dt(a), dt(out), int(trans_a), int(trans_b), M, N, K, ptr(a), lda, ptr(b), ldb,
                        ptr(out), _2d(out), epilogue, float(alpha), ptr(bias), ptr(residual),
                        _2d(residual) if residual is not None else 0, ptr(aux), _2d(aux) if aux is not None else 0,
-                       int(split_k), float(drop_p), int(drop_seed)), "mdt_gemm")
+                       int(split_k), float(drop_p), int(drop_seed), ptr(colsum)), "mdt_gemm")
     return out
 
 
@@ -78,13 +81,20 @@ def layernorm_fwd(x, gamma, beta, eps, out=None):
     return out, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, add=None, dgamma=None, dbeta=None, dx=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, add=None, dgamma=None, dbeta=None, dx=None, drop_p=0.0, drop_seed=0,
+                  colsum=None, want_dropped=False):
+    """→ dx, or (dx, dxd) with ``want_dropped`` (dxd = dx through the hidden-dropout mask); ``colsum`` (fp32[D])
+    accumulates the column sums of dxd (dx when no dropout) — the upstream dense layer's bias gradient."""
     rows, D = x.shape
     if dx is None:
         dx = torch.empty_like(x)
+    dxd = torch.empty_like(x) if (want_dropped and drop_p > 0.0) else None
     check(lib.mdt_layernorm_bwd(stream(), dt(x), rows, D, ptr(dy), _2d(dy), ptr(x), _2d(x), ptr(gamma), ptr(mean),
                                 ptr(rstd), ptr(add), _2d(add) if add is not None else 0, ptr(dx), _2d(dx),
-                                ptr(dgamma), ptr(dbeta)), "mdt_layernorm_bwd")
+                                ptr(dgamma), ptr(dbeta), ptr(dxd), _2d(dxd) if dxd is not None else 0, float(drop_p),
+                                int(drop_seed), ptr(colsum)), "mdt_layernorm_bwd")
+    if want_dropped:
+        return dx, (dxd if dxd is not None else dx)
     return dx
 
 

@@ -35,7 +35,7 @@ def test_header_symbols_exported(lib):
 
 def test_error_reporting(lib):
     # argument validation happens on the host before any launch
-    st = lib.lib.mdt_gemm(None, 7, 0, 0, 0, 4, 4, 4, None, 4, None, 4, None, 4, 0, 1.0, None, None, 0, None, 0, 1, 0.0, 0)
+    st = lib.lib.mdt_gemm(None, 7, 0, 0, 0, 4, 4, 4, None, 4, None, 4, None, 4, 0, 1.0, None, None, 0, None, 0, 1, 0.0, 0, None)
     assert st == -1
     assert b"dtype" in lib.lib.mdt_last_error_string()
 
