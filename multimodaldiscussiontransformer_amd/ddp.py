@@ -34,6 +34,10 @@ class GradientBucketer:
         self.pg = process_group
         self.comm_stream = comm_stream
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # MDT_DDP_FORCE=1: issue the collectives even at world size 1 (exercises the RCCL / side-stream path
+        # on a single-GPU box; an all-reduce over one rank is the identity)
+        import os
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("MDT_DDP_FORCE") == "1")
         self.order_observed: List[int] = []       # ids in completion order (first backward)
         self.layout_final = False
         self.aligned = flat.numel() == sum((p.numel() + 63) // 64 * 64 for p in self.params)
@@ -91,7 +95,7 @@ class GradientBucketer:
             self.ready[i] = True
         while self.cursor < len(self.slots) and self.ready[self.cursor]:
             self.cursor += 1
-        if self.world > 1 and self.layout_final:
+        if self.active and self.layout_final:
             end = self.slots[self.cursor - 1][1] + self.slots[self.cursor - 1][2] if self.cursor else 0
             if end - self.launched >= self.bucket_elems:
                 self._launch(self.launched, end)
@@ -113,7 +117,7 @@ class GradientBucketer:
     def finish(self, scalars: Optional[torch.Tensor] = None, sample_size_index: int = 1):
         """End of backward: reduce what is left, wait, scale by 1 / global sample size.
         ``scalars`` (fp32 vector: loss, sample_size, counters...) is summed over ranks in place."""
-        if self.world > 1:
+        if self.active:
             self._launch(self.launched, self.flat.numel())
             if scalars is not None:
                 self.handles.append(dist.all_reduce(scalars, group=self.pg, async_op=True) if self.comm_stream is None
