@@ -565,8 +565,15 @@ static int dispatch(hipStream_t st, const AttnParams& p) {
   const mdt_attn_fwd_args& a = p.f;
   const bool st_bias = a.attn_bias != nullptr;
   if (a.dtype == MDT_BF16) {
-    if (a.hd == 64 && getenv("MDT_ATTN_V1") == nullptr && (!BWD || getenv("MDT_ATTN_V2_BWD") != nullptr))
-      return attention_v2_dispatch(st, p, BWD);   // fwd: register-resident P
+    if (a.hd == 64 && getenv("MDT_ATTN_V1") == nullptr) {
+      if (!BWD) return attention_v2_dispatch(st, p, false);              // forward: register-resident P
+      // backward, measured at C2 shapes (profiles/round1_attention_v2.txt): S <= 112 -> whole-row v2,
+      // longer sequences -> chunked v3; tiny graphs (S <= 80) stay on the LDS-scratch kernel below
+      const char* force = getenv("MDT_ATTN_BWD");      // "v1" | "v2" | "v3" for A/B runs
+      const bool v1 = force ? !strcmp(force, "v1") : a.S <= 80;
+      const bool v2 = force ? !strcmp(force, "v2") : a.S <= 112;
+      if (!v1) return v2 ? attention_v2_dispatch(st, p, true) : attention_v3_bwd_dispatch(st, p);
+    }
     if (a.hd == 64) return st_bias ? dispatch_nt<bf16_t, 64, true, BWD>(st, p) : dispatch_nt<bf16_t, 64, false, BWD>(st, p);
     set_error("attention(bf16): head_dim %d unsupported (64 only)", a.hd);
     return MDT_ERR_UNSUPPORTED;

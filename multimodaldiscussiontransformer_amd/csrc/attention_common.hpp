@@ -49,5 +49,6 @@ __device__ __forceinline__ float pair_bias(const BiasCtx& b, int q, int key) {
 }
 
 int attention_v2_dispatch(hipStream_t st, const AttnParams& p, bool bwd);
+int attention_v3_bwd_dispatch(hipStream_t st, const AttnParams& p);
 
 }  // namespace mdt

@@ -363,6 +363,248 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
 
 #endif  // MDT_ATTN_V2_BWD
 
+// ---------------------------------------------------------------------------- backward, chunked (v3)
+// With the forward log-sum-exp saved and delta = rowsum(dO * O) (valid with dropout too: O = D V),
+// P and dS are local to a key / query chunk, so the backward never needs a whole row of scores at
+// once.  Both passes walk 64-wide chunks (two K = 32 operand pairs) with the v2 register-resident
+// operands: 8 score / gradient accumulator tiles live instead of 2 x NT, which is what brings the
+// kernel from 1 to 3-4 waves per SIMD — these sequences are short and the kernel is latency-bound.
+//   pass A (queries on lanes): for each key chunk: S^T, dP^T -> dS^T -> dQ^T += K^T dS^T
+//   pass B (keys on lanes):    for each query chunk: S, dP -> P, dS -> dV^T += dO^T P, dK^T += Q^T dS
+template <int HD, bool STRUCT, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pad) {
+  constexpr int ND = HD / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const mdt_attn_fwd_args& a = P.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, seq = blockIdx.y;
+  const int S = a.S, D = a.H * HD;
+  const int64_t row0 = (int64_t)seq * a.seq_stride;
+  const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * a.ld_qkv + h * HD;
+  const bf16_t* dout = (const bf16_t*)P.dout + row0 * P.ld_dout + h * HD;
+  const bf16_t* outp = (const bf16_t*)a.out + row0 * a.ld_out + h * HD;
+  bf16_t* dqkv = (bf16_t*)P.dqkv + row0 * P.ld_dqkv + h * HD;
+  const int64_t tld = a.pos_stride * a.ld_qkv, dld = a.pos_stride * P.ld_dout, old_ = a.pos_stride * a.ld_out,
+                gld = a.pos_stride * P.ld_dqkv;
+  bf16_t* img0 = (bf16_t*)smem;
+  bf16_t* img1 = img0 + s_pad * V2_LD;
+  float* s_kb = (float*)(img1 + s_pad * V2_LD);
+  float* s_lse = s_kb + s_pad;
+  float* s_delta = s_lse + s_pad;
+  float* s_hist = s_delta + s_pad;
+  const int nhist = STRUCT ? ((a.num_spatial + 1 + 3) & ~3) : 0;
+  BiasCtx bc{seq, h, S, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
+  v2_stage<HD>(img0, qkv + D, tld, S, s_pad, tid);      // K
+  v2_stage<HD>(img1, qkv + 2 * D, tld, S, s_pad, tid);  // V
+  for (int i = tid; i < s_pad; i += 256) {
+    s_kb[i] = key_only_bias<bf16_t>(bc, i);
+    float l = -INFINITY, de = 0.f;
+    if (i < S) {
+      l = a.lse[((int64_t)seq * a.H + h) * S + i];
+#pragma unroll
+      for (int c8 = 0; c8 < HD / 8; ++c8) {
+        const bf16x8 o = *(const bf16x8*)(outp + i * old_ + c8 * 8);
+        const bf16x8 g_ = *(const bf16x8*)(dout + i * dld + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) de += (float)o[e] * (float)g_[e];
+      }
+    }
+    s_lse[i] = l;
+    s_delta[i] = de;
+  }
+  for (int i = tid; i < nhist; i += 256) s_hist[i] = 0.f;
+  __syncthreads();
+  const uint32_t drop_base = (uint32_t)((seq * a.H + h) * S) * (uint32_t)S;
+  const int g = lane >> 4, c = lane & 15;
+  const int n_t = (S + 15) >> 4;
+  const int n_chunk = s_pad >> 6;           // 64-wide chunks (s_pad is a multiple of 64)
+
+  // ------------------------------------------------------------------ pass A
+  for (int qt = wave; qt < n_t; qt += 4) {
+    const int q0 = qt * 16;
+    const int q = q0 + c;
+    const bool qok = q < S;
+    const int qc = qok ? q : S - 1;
+    bf16x8 fq[HD / 32], fo[HD / 32];
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      fq[ks] = v2_frag_glb(qkv, tld, S, q0, ks * 32, lane);
+      fo[ks] = v2_frag_glb(dout, dld, S, q0, ks * 32, lane);
+    }
+    const float l = s_lse[qc], del = s_delta[qc];
+    f32x4 dq[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < n_chunk; ++ch) {
+      const int t0 = ch * 4;
+      f32x4 sc[4], dp[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { sc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) {
+          sc[t] = mfma_bf16(v2_frag_lds(img0, (t0 + t) * 16, ks * 32, lane), fq[ks], sc[t]);
+          dp[t] = mfma_bf16(v2_frag_lds(img1, (t0 + t) * 16, ks * 32, lane), fo[ks], dp[t]);
+          if (ks == HD / 32 - 1 && (t & 1)) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = (t0 + t) * 16 + 4 * g + r;
+          float v = sc[t][r] * a.scale + s_kb[key];
+          if ((a.dense_bias || STRUCT) && key < S) v += pair_bias<bf16_t, STRUCT>(bc, qc, key);
+          const float p = (v == -INFINITY || l == -INFINITY || !qok) ? 0.f : __expf(v - l);
+          float dpe = dp[t][r];
+          if constexpr (DROP) dpe *= drop_scale(P.drop, (uint64_t)(drop_base + (uint32_t)(q * S + key)));
+          const float ds = p * (dpe - del);
+          sc[t][r] = ds;
+          if (qok && key < S) {
+            if (P.d_dense_bias) P.d_dense_bias[(((int64_t)seq * a.H + h) * S + q) * S + key] = ds;
+            if constexpr (STRUCT) {
+              if (P.d_sp_table && ds != 0.f) {
+                if (q >= 1 && key >= 1) {
+                  const int idx = a.spatial_pos[((int64_t)seq * (S - 1) + (q - 1)) * (S - 1) + (key - 1)];
+                  if (idx != 0) atomicAdd(s_hist + idx, ds);
+                } else {
+                  atomicAdd(s_hist + a.num_spatial, ds);
+                }
+              }
+            }
+          }
+        }
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        const bf16x8 fs = v2_pack(sc[2 * pi], sc[2 * pi + 1]);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) dq[d] = mfma_bf16(v2_frag_tr(img0, t0 + 2 * pi, d * 16, lane), fs, dq[d]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (qok) {
+      bf16_t* orow = dqkv + (int64_t)q * gld + 4 * g;
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+        *(bf16x4*)(orow + d * 16) = bf16x4{(bf16_t)(dq[d][0] * a.scale), (bf16_t)(dq[d][1] * a.scale),
+                                           (bf16_t)(dq[d][2] * a.scale), (bf16_t)(dq[d][3] * a.scale)};
+    }
+  }
+  __syncthreads();   // K / V images are free
+  v2_stage<HD>(img0, qkv, tld, S, s_pad, tid);    // Q
+  v2_stage<HD>(img1, dout, dld, S, s_pad, tid);   // dO
+  if constexpr (STRUCT) {
+    if (P.d_sp_table) {
+      for (int i = tid; i <= a.num_spatial; i += 256) {
+        const float v = s_hist[i];
+        if (v != 0.f) {
+          if (i < a.num_spatial) atomicAdd(P.d_sp_table + (int64_t)i * a.H + h, v);
+          else if (P.d_virt) atomicAdd(P.d_virt + h, v);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ------------------------------------------------------------------ pass B
+  for (int kt = wave; kt < n_t; kt += 4) {
+    const int key0 = kt * 16;
+    const int key = key0 + c;
+    const bool kok = key < S;
+    const float kb = s_kb[key];
+    bf16x8 fk[HD / 32], fv[HD / 32];
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      fk[ks] = v2_frag_glb(qkv + D, tld, S, key0, ks * 32, lane);
+      fv[ks] = v2_frag_glb(qkv + 2 * D, tld, S, key0, ks * 32, lane);
+    }
+    f32x4 dv[ND], dk[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) { dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int ch = 0; ch < n_chunk; ++ch) {
+      const int t0 = ch * 4;
+      f32x4 sc[4], dp[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { sc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) {
+          sc[t] = mfma_bf16(v2_frag_lds(img0, (t0 + t) * 16, ks * 32, lane), fk[ks], sc[t]);   // S[q][key]
+          dp[t] = mfma_bf16(v2_frag_lds(img1, (t0 + t) * 16, ks * 32, lane), fv[ks], dp[t]);   // dP[q][key]
+          if (ks == HD / 32 - 1 && (t & 1)) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = (t0 + t) * 16 + 4 * g + r;
+          const bool qok = q < S;
+          const int qc = qok ? q : S - 1;
+          float v = sc[t][r] * a.scale + kb;
+          if ((a.dense_bias || STRUCT) && kok) v += pair_bias<bf16_t, STRUCT>(bc, qc, key);
+          const float l = s_lse[q];
+          const float p = (v == -INFINITY || l == -INFINITY || !qok || !kok) ? 0.f : __expf(v - l);
+          float ds = dp[t][r];
+          float pd = p;
+          if constexpr (DROP) {
+            const float m = drop_scale(P.drop, (uint64_t)(drop_base + (uint32_t)(qc * S + key)));
+            ds *= m;
+            pd *= m;
+          }
+          sc[t][r] = pd;
+          dp[t][r] = p * (ds - s_delta[q]);
+        }
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        const bf16x8 fp = v2_pack(sc[2 * pi], sc[2 * pi + 1]);
+        const bf16x8 fs = v2_pack(dp[2 * pi], dp[2 * pi + 1]);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+          dv[d] = mfma_bf16(v2_frag_tr(img1, t0 + 2 * pi, d * 16, lane), fp, dv[d]);
+          dk[d] = mfma_bf16(v2_frag_tr(img0, t0 + 2 * pi, d * 16, lane), fs, dk[d]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (kok) {
+      bf16_t* krow = dqkv + (int64_t)key * gld + D + 4 * g;
+      bf16_t* vrow = dqkv + (int64_t)key * gld + 2 * D + 4 * g;
+#pragma unroll
+      for (int d = 0; d < ND; ++d) {
+        *(bf16x4*)(krow + d * 16) = bf16x4{(bf16_t)(dk[d][0] * a.scale), (bf16_t)(dk[d][1] * a.scale),
+                                           (bf16_t)(dk[d][2] * a.scale), (bf16_t)(dk[d][3] * a.scale)};
+        *(bf16x4*)(vrow + d * 16) = bf16x4{(bf16_t)dv[d][0], (bf16_t)dv[d][1], (bf16_t)dv[d][2], (bf16_t)dv[d][3]};
+      }
+    }
+  }
+}
+
+template <bool STRUCT, bool DROP>
+static int launch_v3(hipStream_t st, const AttnParams& p) {
+  const int s_pad = (p.f.S + 63) & ~63;
+  const int nhist = STRUCT ? ((p.f.num_spatial + 1 + 3) & ~3) : 0;
+  const size_t lds = (size_t)2 * s_pad * V2_LD * 2 + (size_t)3 * s_pad * 4 + (size_t)nhist * 4;
+  if (lds > 160 * 1024) { set_error("attention_bwd_v3: S=%d needs %zu bytes of LDS", p.f.S, lds); return MDT_ERR_UNSUPPORTED; }
+  auto kern = attn_bwd_v3_kernel<64, STRUCT, DROP>;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("attention_bwd_v3: cannot reserve %zu bytes of LDS", lds);
+      return MDT_ERR_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(p.f.H, p.f.nseq), 256, lds, st, p, s_pad);
+  return check_launch("attention_bwd_v3");
+}
+
+int attention_v3_bwd_dispatch(hipStream_t st, const AttnParams& p) {
+  const bool s = p.f.attn_bias != nullptr, d = p.f.drop_p > 0.f;
+  if (s && d) return launch_v3<true, true>(st, p);
+  if (s) return launch_v3<true, false>(st, p);
+  if (d) return launch_v3<false, true>(st, p);
+  return launch_v3<false, false>(st, p);
+}
+
 template <int NT, bool STRUCT, bool DROP, bool BWD>
 static int launch_v2(hipStream_t st, const AttnParams& p) {
   constexpr int S_PAD = ((NT + 1) / 2) * 32;

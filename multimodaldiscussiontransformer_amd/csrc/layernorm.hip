@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int D,
 // Backward: each wave walks rows_per_wave consecutive rows, keeps per-lane partial
 // dgamma / dbeta in registers, the block combines them through LDS and issues one
 // float atomic per column.
-template <typename T, int NV>
+template <typename T, int NV, bool TAIL>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D, const T* __restrict__ dy, int64_t lddy,
                                                             const T* __restrict__ x, int64_t ldx,
                                                             const T* __restrict__ gamma, const float* __restrict__ mean,
@@ -132,17 +132,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
           float v = rs * (gy[i].get(j) * gv[i].get(j) - m1 - xh * m2);
           if (add) v += a.get(j);
           o.set(j, v);
-          if (dxd) {   // second output: the gradient of the dense layer behind a hidden dropout
-            v = o.get(j) * drop_scale(drop, (uint64_t)row * D + c + j);
-            od.set(j, v);
-            v = od.get(j);
-          } else {
-            v = o.get(j);
+          if constexpr (TAIL) {
+            if (dxd) {   // second output: the gradient of the dense layer behind a hidden dropout
+              v = o.get(j) * drop_scale(drop, (uint64_t)row * D + c + j);
+              od.set(j, v);
+              v = od.get(j);
+            } else {
+              v = o.get(j);
+            }
+            pc[i][j] += v;
           }
-          pc[i][j] += v;
         }
         *(Vec<T>*)(dx + row * lddx + c) = o;
-        if (dxd) *(Vec<T>*)(dxd + row * lddxd + c) = od;
+        if constexpr (TAIL) {
+          if (dxd) *(Vec<T>*)(dxd + row * lddxd + c) = od;
+        }
       }
     }
   }
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
       const int c = (i * 64 + lane) * VN + j;
       red[wave * W + c] = pg[i][j];
       red[(4 + wave) * W + c] = pb[i][j];
-      red[(8 + wave) * W + c] = pc[i][j];
+      if constexpr (TAIL) red[(8 + wave) * W + c] = pc[i][j];
     }
   __syncthreads();
   for (int c = threadIdx.x; c < D; c += 256) {
@@ -163,7 +167,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
     const float b = red[4 * W + c] + red[5 * W + c] + red[6 * W + c] + red[7 * W + c];
     if (dgamma) atomicAdd(dgamma + c, g);
     if (dbeta) atomicAdd(dbeta + c, b);
-    if (colsum) atomicAdd(colsum + c, red[8 * W + c] + red[9 * W + c] + red[10 * W + c] + red[11 * W + c]);
+    if constexpr (TAIL) {
+      if (colsum) atomicAdd(colsum + c, red[8 * W + c] + red[9 * W + c] + red[10 * W + c] + red[11 * W + c]);
+    }
   }
 }
 
@@ -200,10 +206,16 @@ static int ln_bwd_dispatch(hipStream_t st, int64_t rows, int D, const void* dy, 
   int rpw = (int)((rows + 2048 * 4 - 1) / (2048 * 4));
   if (rpw < 4) rpw = 4;
   const unsigned grid = (unsigned)((rows + 4 * rpw - 1) / (4 * rpw));
+  const bool tail = dxd != nullptr || colsum != nullptr;
 #define LN_BWD(NV_)                                                                                              \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV_>), grid, 256, (size_t)(12 * NV_ * 64 * VN * 4), st, rows, D,   \
-                     (const T*)dy, lddy, (const T*)x, ldx, (const T*)gamma, mean, rstd, (const T*)add, ldadd,    \
-                     (T*)dx, lddx, dgamma, dbeta, rpw, (T*)dxd, lddxd, drop, colsum)
+  if (tail)                                                                                                      \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV_, true>), grid, 256, (size_t)(12 * NV_ * 64 * VN * 4), st, rows, D, \
+                       (const T*)dy, lddy, (const T*)x, ldx, (const T*)gamma, mean, rstd, (const T*)add, ldadd,  \
+                       (T*)dx, lddx, dgamma, dbeta, rpw, (T*)dxd, lddxd, drop, colsum);                          \
+  else                                                                                                           \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV_, false>), grid, 256, (size_t)(8 * NV_ * 64 * VN * 4), st, rows, D, \
+                       (const T*)dy, lddy, (const T*)x, ldx, (const T*)gamma, mean, rstd, (const T*)add, ldadd,  \
+                       (T*)dx, lddx, dgamma, dbeta, rpw, (T*)dxd, lddxd, drop, colsum)
   switch (nv) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;

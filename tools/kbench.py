@@ -85,13 +85,19 @@ def rest(M, dev, bf):
         ex = {}
         if name == "graph":
             ex = dict(d_sp_table=torch.zeros(512, H, device=dev), d_virt=torch.zeros(H, device=dev))
-        t = timeit(lambda: ops.attention_bwd(dout, qkv, out, lse, nseq, S, H, **kw, **ex))
-        print(f"{name:6s} bwd: {t*1e3:8.3f} ms  {2.5*fl/t/1e12:7.1f} TF/s (algorithmic 10 S^2 d)")
         import os
-        os.environ["MDT_ATTN_V2_BWD"] = "1"
+        os.environ["MDT_ATTN_BWD"] = "v1"
         t = timeit(lambda: ops.attention_bwd(dout, qkv, out, lse, nseq, S, H, **kw, **ex))
-        os.environ.pop("MDT_ATTN_V2_BWD")
+        os.environ.pop("MDT_ATTN_BWD")
+        print(f"{name:6s} bwd (v1): {t*1e3:8.3f} ms  {2.5*fl/t/1e12:7.1f} TF/s (algorithmic 10 S^2 d)")
+        os.environ["MDT_ATTN_BWD"] = "v2"
+        t = timeit(lambda: ops.attention_bwd(dout, qkv, out, lse, nseq, S, H, **kw, **ex))
+        os.environ.pop("MDT_ATTN_BWD")
         print(f"{name:6s} bwd (v2): {t*1e3:8.3f} ms  {2.5*fl/t/1e12:7.1f} TF/s")
+        os.environ["MDT_ATTN_BWD"] = "v3"
+        t = timeit(lambda: ops.attention_bwd(dout, qkv, out, lse, nseq, S, H, **kw, **ex))
+        os.environ.pop("MDT_ATTN_BWD")
+        print(f"{name:6s} bwd (v3): {t*1e3:8.3f} ms  {2.5*fl/t/1e12:7.1f} TF/s")
     print("== layernorm bf16 ==")
     x = torch.randn(M, 768, device=dev, dtype=bf); g = torch.ones(768, device=dev, dtype=bf); bb = torch.zeros(768, device=dev, dtype=bf)
     y, mean, rstd = ops.layernorm_fwd(x, g, bb, 1e-12)
