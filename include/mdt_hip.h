@@ -213,6 +213,15 @@ int mdt_cast(void* stream, int src_dtype, int dst_dtype, int64_t n, const void* 
 int mdt_transpose2d(void* stream, int src_dtype, int dst_dtype, int64_t rows, int64_t cols,
                     const void* src, int64_t lds, void* dst, int64_t ldd);
 
+/* ------------------------------------------------------------------ optimiser (the step after the path)
+ * Fused Adam with FairSeq semantics over one tensor: g = grad * (*grad_scale if given);
+ * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= wd*lr*p; p -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v)+eps).
+ * `master` (fp32, optional) is the high-precision copy of a bf16 `param`.  grad_scale is a DEVICE scalar
+ * (e.g. 1 / global sample size) so no host synchronisation is needed. */
+int mdt_adam_step(void* stream, int dtype, int64_t n, void* param, float* master, const float* grad, float* m,
+                  float* v, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  const float* grad_scale);
+
 /* ------------------------------------------------------------------ packer (host, C++)
  * Native replacement of preprocess_item + collator (data/pyg_datasets/pre_processing.py:18-69,
  * data/collator.py:69-179): integer tensors are bit-exact with the reference.

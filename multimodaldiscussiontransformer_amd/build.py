@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmdt_hip.so")
-SOURCES = ["gemm.hip", "layernorm.hip", "attention.hip", "attention_v2.hip", "rowops.hip", "host.cpp"]
+SOURCES = ["gemm.hip", "layernorm.hip", "attention.hip", "attention_v2.hip", "rowops.hip", "optim.hip", "host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-ffp-contract=off"]
 
 

@@ -40,6 +40,7 @@ class GradientBucketer:
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("MDT_DDP_FORCE") == "1")
         self.order_observed: List[int] = []       # ids in completion order (first backward)
         self.layout_final = False
+        self.sync_this_backward = True
         self.aligned = flat.numel() == sum((p.numel() + 63) // 64 * 64 for p in self.params)
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._assign_views(self.params)
@@ -86,6 +87,8 @@ class GradientBucketer:
 
     def on_params_ready(self, params):
         """Tape hook: the gradients of ``params`` are final for this step."""
+        if not self.sync_this_backward:      # gradient accumulation: only the last micro-batch is reduced
+            return
         for p in params:
             i = self._pos.get(id(p))
             if i is None:
@@ -153,6 +156,10 @@ class DataParallel:
 
     def zero_grad(self):
         self.model.main_grad_flat.zero_()
+
+    def accumulate(self, last_micro_batch: bool):
+        """--update-freq: call before each micro-batch's backward; overlapped all-reduce only on the last one."""
+        self.bucketer.sync_this_backward = bool(last_micro_batch)
 
     def finish_backward(self, logging_scalars: Optional[torch.Tensor] = None):
         self.bucketer.finish(logging_scalars)

@@ -1,0 +1,59 @@
+"""Optimiser + LR schedule of the reference launch (FairSeq `adam` + `polynomial_decay`,
+mDT/experiments/hateful_discussions/run_train.sh:38-40), fused: one HIP kernel per parameter
+tensor reads the fp32 gradient arena and updates moments, fp32 master weights and the
+working-precision parameter in a single pass."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from ._lib import check, dt, lib, ptr, stream
+
+
+class FusedAdam:
+    def __init__(self, params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        self.params = [p for p in params if p.requires_grad]
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.step_count = 0
+        self.state = {}
+        for p in self.params:
+            st = dict(m=torch.zeros(p.shape, dtype=torch.float32, device=p.device),
+                      v=torch.zeros(p.shape, dtype=torch.float32, device=p.device))
+            if p.dtype != torch.float32:
+                st["master"] = p.detach().float().clone()
+            self.state[id(p)] = st
+
+    def step(self, lr=None, grad_scale: torch.Tensor = None):
+        """Gradients are read from ``p.main_grad`` (fp32 arena) or ``p.grad``; ``grad_scale`` is an optional
+        fp32 device scalar multiplied into every gradient."""
+        self.step_count += 1
+        lr = self.lr if lr is None else lr
+        for p in self.params:
+            g = getattr(p, "main_grad", None)
+            if g is None:
+                g = p.grad
+                if g is None:
+                    continue
+                if g.dtype != torch.float32:
+                    g = g.float()
+            st = self.state[id(p)]
+            check(lib.mdt_adam_step(stream(), dt(p), p.numel(), ptr(p.data), ptr(st.get("master")), ptr(g.contiguous()),
+                                    ptr(st["m"]), ptr(st["v"]), float(lr), float(self.betas[0]), float(self.betas[1]),
+                                    float(self.eps), float(self.weight_decay), self.step_count, ptr(grad_scale)),
+                  "mdt_adam_step")
+
+
+class PolynomialDecayLR:
+    """FairSeq ``polynomial_decay``: linear warm-up to ``lr`` over ``warmup_updates`` then
+    (lr - end_lr) * (1 - progress)^power + end_lr until ``total_num_update``."""
+
+    def __init__(self, lr=3e-5, end_lr=3e-7, warmup_updates=3246, total_num_update=10820, power=1.0):
+        self.lr, self.end_lr, self.warmup, self.total, self.power = lr, end_lr, warmup_updates, total_num_update, power
+
+    def __call__(self, num_updates: int) -> float:
+        if self.warmup > 0 and num_updates <= self.warmup:
+            return self.lr * num_updates / float(self.warmup)
+        if num_updates >= self.total:
+            return self.end_lr
+        pct = 1 - (num_updates - self.warmup) / float(self.total - self.warmup)
+        return (self.lr - self.end_lr) * pct ** self.power + self.end_lr
