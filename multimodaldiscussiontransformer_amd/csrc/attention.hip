@@ -570,8 +570,9 @@ static int dispatch(hipStream_t st, const AttnParams& p) {
       // backward, measured at C2 shapes (profiles/round1_attention_v2.txt): S <= 112 -> whole-row v2,
       // longer sequences -> chunked v3; tiny graphs (S <= 80) stay on the LDS-scratch kernel below
       const char* force = getenv("MDT_ATTN_BWD");      // "v1" | "v2" | "v3" for A/B runs
-      const bool v1 = force ? !strcmp(force, "v1") : a.S <= 80;
-      const bool v2 = force ? !strcmp(force, "v2") : a.S <= 112;
+      const bool drop = a.drop_p > 0.f;                // with dropout the whole-row v2 falls to 1 wave / SIMD
+      const bool v1 = force ? !strcmp(force, "v1") : (a.S <= 80 || (drop && a.S <= 112));
+      const bool v2 = force ? !strcmp(force, "v2") : (!drop && a.S <= 112);
       if (!v1) return v2 ? attention_v2_dispatch(st, p, true) : attention_v3_bwd_dispatch(st, p);
     }
     if (a.hd == 64) return st_bias ? dispatch_nt<bf16_t, 64, true, BWD>(st, p) : dispatch_nt<bf16_t, 64, false, BWD>(st, p);

@@ -235,7 +235,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
         *(bf16x8*)((bf16_t*)p.aux + gr * p.ldaux + gc) = u;
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+      for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
     }
     if (ep & MDT_EPI_DROPOUT) {
 #pragma unroll
@@ -244,7 +244,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
     if (ep & MDT_EPI_DGELU) {
       const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + gr * p.ldaux + gc);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad((float)u[e]);
+      for (int e = 0; e < 8; ++e) v[e] *= gelu_fast_grad((float)u[e]);
     }
     if (ep & MDT_EPI_RESIDUAL) {
       const bf16x8 r = *(const bf16x8*)((const bf16_t*)p.residual + gr * p.ldr + gc);
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_tile256(GemmParams p) {
 //        barrier that pairs those two.  WAR: the loads of tile kt+1 are issued in READ 0 of tile
 //        kt, after the barrier behind which the late group completed (lgkmcnt(0)) its last reads
 //        of tile kt-1.
-template <typename TOut, bool A_KM, bool B_KM>
+template <typename TOut, bool A_KM, bool B_KM, int PHASES>
 __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
   constexpr int BM = 256, BN = 256;
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
@@ -528,33 +528,60 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
   for (int kt = 0; kt < nk; ++kt) {
     const char* cur = smem + (kt & 1) * STAGE;
     bf16x8 b[4];
+    if constexpr (PHASES == 4) {
 #pragma unroll
-    for (int ph = 0; ph < 4; ++ph) {
-      const int ks = ph >> 1, mh = ph & 1;
-      // ---------------- READ segment
-      bf16x8 a[4];
-      if (mh == 0) {
+      for (int ph = 0; ph < 4; ++ph) {
+        const int ks = ph >> 1, mh = ph & 1;
+        // ---------------- READ segment
+        bf16x8 a[4];
+        if (mh == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[j] = load_frag<B_KM, BN>(cur + A_BYTES, wc * 64 + j * 16, ks, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = load_frag<A_KM, BM>(cur, wr * 128 + mh * 64 + i * 16, ks, lane);
+        if (ph == 0 && kt + 1 < nk) issue(kt + 1);
+        if (ph == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- MFMA segment
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[mh * 4 + i][j] = mfma_bf16(a[i], b[j], acc[mh * 4 + i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // two phases of 32 MFMAs (one per k-step): half the barriers, 48 fragment registers
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j] = load_frag<B_KM, BN>(cur + A_BYTES, wc * 64 + j * 16, ks, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = load_frag<A_KM, BM>(cur, wr * 128 + i * 16, ks, lane);
+        if (ks == 0 && kt + 1 < nk) issue(kt + 1);
+        if (ks == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(a[i], b[j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = load_frag<A_KM, BM>(cur, wr * 128 + mh * 64 + i * 16, ks, lane);
-      if (ph == 0 && kt + 1 < nk) issue(kt + 1);
-      if (ph == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---------------- MFMA segment
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[mh * 4 + i][j] = mfma_bf16(a[i], b[j], acc[mh * 4 + i][j]);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (!late) __builtin_amdgcn_s_barrier();     // equalise the barrier count of the two groups
@@ -702,9 +729,9 @@ template <typename TOut>
 static int launch_pp256(hipStream_t st, const GemmParams& p, int ta, int tb) {
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)p.split_k);
   const size_t lds = (size_t)2 * 512 * 128;
-#define LPP(A_, B_)                                                                                          \
+#define LPP(A_, B_, PH_)                                                                                        \
   {                                                                                                          \
-    auto kern = gemm_bf16_pp256<TOut, A_, B_>;                                                               \
+    auto kern = gemm_bf16_pp256<TOut, A_, B_, PH_>;                                                          \
     static bool attr_set = false;                                                                            \
     if (!attr_set) {                                                                                         \
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
@@ -716,10 +743,18 @@ static int launch_pp256(hipStream_t st, const GemmParams& p, int ta, int tb) {
     }                                                                                                        \
     hipLaunchKernelGGL(kern, grid, 512, lds, st, p);                                                         \
   }
-  if (!ta && !tb) LPP(false, false)
-  else if (!ta && tb) LPP(false, true)
-  else if (ta && !tb) LPP(true, false)
-  else LPP(true, true)
+  const bool two = getenv("MDT_GEMM_PP_PHASES") == nullptr || atoi(getenv("MDT_GEMM_PP_PHASES")) == 2;   // measured: 2 phases of 32 MFMAs beat 4 x 16 by 3-10 %
+  if (two) {
+    if (!ta && !tb) LPP(false, false, 2)
+    else if (!ta && tb) LPP(false, true, 2)
+    else if (ta && !tb) LPP(true, false, 2)
+    else LPP(true, true, 2)
+  } else {
+    if (!ta && !tb) LPP(false, false, 4)
+    else if (!ta && tb) LPP(false, true, 4)
+    else if (ta && !tb) LPP(true, false, 4)
+    else LPP(true, true, 4)
+  }
 #undef LPP
   return check_launch("gemm_bf16_pp256");
 }

@@ -55,8 +55,8 @@ def build_parser():
     p.add_argument("--update-freq", type=int, default=1)
     p.add_argument("--max-epoch", type=int, default=0)
     p.add_argument("--max-update", type=int, default=0)
-    p.add_argument("--fp16", action="store_true", help="the reference's half precision; runs as bf16 here")
-    p.add_argument("--bf16", action="store_true")
+    p.add_argument("--fp16", action="store_true", default=False, help="the reference's half precision; runs as bf16 here")
+    p.add_argument("--bf16", action="store_true", default=False)
     p.add_argument("--log-interval", type=int, default=10)
     p.add_argument("--positive-weight", type=float, default=1.0)
     p.add_argument("--negative-weight", type=float, default=1.0)
@@ -74,7 +74,7 @@ def build_parser():
     for f in TaskConfig.__dataclass_fields__.values():
         flag = "--" + f.name.replace("_", "-")
         if f.type in (bool, "bool"):
-            p.add_argument(flag, action="store_true")
+            p.add_argument(flag, action="store_true", default=False)
         else:
             p.add_argument(flag, type=type(f.default), default=f.default)
     MODEL_REGISTRY["multi_graphormer"].add_args(p)

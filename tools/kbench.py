@@ -26,12 +26,13 @@ def main():
     bf = torch.bfloat16
     M = 212992
     import os
-    for force in ("256x256", "pp"):
+    for force, ph in (("pp", "4"), ("pp", "2")):
+        os.environ["MDT_GEMM_PP_PHASES"] = ph
         if force is None:
             os.environ.pop("MDT_GEMM_TILE", None)
         else:
             os.environ["MDT_GEMM_TILE"] = force
-        print(f"== GEMM bf16, tile = {force or 'auto'} ==")
+        print(f"== GEMM bf16, tile = {force or 'auto'}, phases = {ph} ==")
         gemm_section(M, dev, bf)
     rest(M, dev, bf)
 
