@@ -571,6 +571,7 @@ static int dispatch(hipStream_t st, const AttnParams& p) {
       // longer sequences -> chunked v3; tiny graphs (S <= 80) stay on the LDS-scratch kernel below
       const char* force = getenv("MDT_ATTN_BWD");      // "v1" | "v2" | "v3" for A/B runs
       const bool drop = a.drop_p > 0.f;                // with dropout the whole-row v2 falls to 1 wave / SIMD
+      if (BWD && a.S > 256 && !force) return attention_v3_bwd_dispatch(st, p);   // ViT-L/14: 4 + 257 tokens
       const bool v1 = force ? !strcmp(force, "v1") : (a.S <= 80 || (drop && a.S <= 112));
       const bool v2 = force ? !strcmp(force, "v2") : (!drop && a.S <= 112);
       if (!v1) return v2 ? attention_v2_dispatch(st, p, true) : attention_v3_bwd_dispatch(st, p);

@@ -635,9 +635,9 @@ template <bool STRUCT, bool DROP, bool BWD>
 static int dispatch_v2_nt(hipStream_t st, const AttnParams& p) {
   const int nt = (p.f.S + 15) / 16;
 #define V2_CASE(N_) if (nt <= N_) return launch_v2<N_, STRUCT, DROP, BWD>(st, p);
-  V2_CASE(2) V2_CASE(5) V2_CASE(7) V2_CASE(9) V2_CASE(13) V2_CASE(16)
+  V2_CASE(2) V2_CASE(5) V2_CASE(7) V2_CASE(9) V2_CASE(13) V2_CASE(17)
 #undef V2_CASE
-  set_error("attention_v2: S=%d exceeds 256", p.f.S);
+  set_error("attention_v2: S=%d exceeds 272", p.f.S);
   return MDT_ERR_UNSUPPORTED;
 }
 

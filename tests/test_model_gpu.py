@@ -279,3 +279,47 @@ def test_full_model_bf16_vs_fp32_oracle(kind):
         if cos < 0.98:
             low.append((name, cos))
     assert not low, low[:8]
+
+
+@pytest.mark.parametrize("kind,S,nseq", [("vit", 261, 3), ("bert", 104, 5)])
+def test_large_shaped_encoder_block_bf16(kind, S, nseq):
+    """mDT-large shapes (config 4: D 1024, 16 heads, ViT-L/14 → 4 + 257 tokens per image): one encoder
+    block forward / backward in bf16 against the fp32 oracle block on bf16-rounded weights."""
+    from multimodaldiscussiontransformer_amd import engine as E
+    from multimodaldiscussiontransformer_amd.modules._fused import BertLayer, ViTLayer
+    D, H, Fe = 1024, 16, 512
+    layer = (ViTLayer if kind == "vit" else BertLayer)(D, H, Fe)
+    pre = "L."
+    sd = {k: torch.from_numpy(hashinit.param(pre + k, tuple(v.shape))) for k, v in layer.state_dict().items()}
+    layer.load_state_dict(sd)
+    layer = layer.cuda().bfloat16()
+    W = {pre + k: v.bfloat16().float().requires_grad_(True) for k, v in sd.items()}
+    x = hu("big/x", (nseq, S, D), 1.0).bfloat16()
+    cot = hu("big/c", (nseq, S, D), 1.0).bfloat16()
+    km = torch.ones(nseq, S, dtype=torch.uint8)
+    if kind == "bert":
+        km[1, S - 9:] = 0
+    xr = x.float().requires_grad_(True)
+    if kind == "vit":
+        yr = R.vit_layer(xr, W, "L", H)
+    else:
+        add = (1.0 - km.float())[:, None, None, :] * float(torch.finfo(torch.half).min)
+        yr = R.bert_layer(xr, W, "L", H, add)
+    (yr * cot.float()).sum().backward()
+    xg = x.cuda().view(nseq * S, D).requires_grad_(True)
+
+    def run(tape, xv):
+        spec = E.AttnSpec(nseq=nseq, S=S, H=H, key_mask=km.cuda() if kind == "bert" else None)
+        return (E.transformer_block(tape, xv, layer.block_params(), spec, pre_ln=layer.pre_ln, eps=layer.eps),)
+
+    (y,) = E.run_tape(run, [xg], list(layer.parameters()))
+    (y.float() * cot.cuda().view(nseq * S, D).float()).sum().backward()
+    assert float((y.float().cpu().view(nseq, S, D) - yr.detach()).abs().max()) < 0.12     # outputs are O(1..5), bf16 eps 0.8 %
+    ref_g = xr.grad
+    got_g = xg.grad.float().cpu().view(nseq, S, D)
+    cos = float((ref_g * got_g).sum() / (ref_g.norm() * got_g.norm()))
+    assert cos > 0.995, cos
+    p = layer.intermediate.dense.weight
+    rg = W[pre + "intermediate.dense.weight"].grad
+    cos = float((rg * p.grad.float().cpu()).sum() / (rg.norm() * p.grad.float().norm().cpu()))
+    assert cos > 0.99, cos
