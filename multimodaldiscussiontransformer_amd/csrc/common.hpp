@@ -114,18 +114,28 @@ __device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t idx) {
   x ^= x >> 15; x *= 0x2c1b3c6dU; x ^= x >> 12; x *= 0x297a2d39U; x ^= x >> 15;
   return x;
 }
+// One 32-bit hash serves the two counters 2i and 2i+1 (16 random bits each), halving the integer work in
+// the vector epilogues; p is realised as round(p * 65536) / 65536 (relative bias of the 1/(1-p) scale < 2e-5).
 struct DropCfg {
   uint64_t seed;
-  uint32_t thresh;   // drop when (hash >> 8) < thresh, thresh = p * 2^24
+  uint32_t thresh;   // drop when the counter's 16 bits < thresh
   float inv_keep;    // 1 / (1 - p)
 };
 __device__ __forceinline__ float drop_scale(const DropCfg& d, uint64_t idx) {
-  return ((drop_hash(d.seed, idx) >> 8) >= d.thresh) ? d.inv_keep : 0.f;
+  const uint32_t h = drop_hash(d.seed, idx >> 1);
+  const uint32_t bits = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
+  return bits >= d.thresh ? d.inv_keep : 0.f;
+}
+// counters idx_even and idx_even + 1 (idx_even must be even)
+__device__ __forceinline__ void drop_scale2(const DropCfg& d, uint64_t idx_even, float& s0, float& s1) {
+  const uint32_t h = drop_hash(d.seed, idx_even >> 1);
+  s0 = (h & 0xFFFFu) >= d.thresh ? d.inv_keep : 0.f;
+  s1 = (h >> 16) >= d.thresh ? d.inv_keep : 0.f;
 }
 static inline DropCfg make_drop(float p, uint64_t seed) {
   DropCfg d;
   d.seed = seed;
-  d.thresh = (uint32_t)(p * 16777216.0f);
+  d.thresh = (uint32_t)(p * 65536.0f + 0.5f);
   d.inv_keep = 1.0f / (1.0f - p);
   return d;
 }

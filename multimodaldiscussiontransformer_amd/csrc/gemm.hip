@@ -237,9 +237,14 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
     }
-    if (ep & MDT_EPI_DROPOUT) {
+    if (ep & MDT_EPI_DROPOUT) {   // N is a multiple of 128 and gc of 8: the 8 counters start even
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= drop_scale(p.drop, (uint64_t)gr * p.N + gc + e);
+      for (int e = 0; e < 8; e += 2) {
+        float s0, s1;
+        drop_scale2(p.drop, (uint64_t)gr * p.N + gc + e, s0, s1);
+        v[e] *= s0;
+        v[e + 1] *= s1;
+      }
     }
     if (ep & MDT_EPI_DGELU) {
       const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + gr * p.ldaux + gc);
@@ -654,6 +659,25 @@ __global__ __launch_bounds__(256) void dropout_kernel(int64_t rows, int D, const
     for (int c = lane; c < D; c += 64)
       y[r * ldy + c] = from_f32<T>(to_f32(x[r * ldx + c]) * drop_scale(d, (uint64_t)r * D + c));
 }
+// 16-byte vector variant (D, strides multiples of VN; D even so every vector starts on an even counter)
+template <typename T, int VN>
+__global__ __launch_bounds__(256) void dropout_vec_kernel(int64_t rows, int D, const T* x, int64_t ldx, T* y, int64_t ldy, DropCfg d) {
+  typedef __attribute__((ext_vector_type(VN))) T vec;
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4)
+    for (int c = lane * VN; c < D; c += 64 * VN) {
+      const vec v = *(const vec*)(x + r * ldx + c);
+      vec o;
+#pragma unroll
+      for (int e = 0; e < VN; e += 2) {
+        float s0, s1;
+        drop_scale2(d, (uint64_t)r * D + c + e, s0, s1);
+        o[e] = from_f32<T>(to_f32((T)v[e]) * s0);
+        o[e + 1] = from_f32<T>(to_f32((T)v[e + 1]) * s1);
+      }
+      *(vec*)(y + r * ldy + c) = o;
+    }
+}
 __global__ void dropout_mask_kernel(int64_t n, DropCfg d, uint8_t* mask) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     mask[i] = drop_scale(d, (uint64_t)i) != 0.f;
@@ -887,6 +911,13 @@ extern "C" int mdt_dropout(void* stream, int dtype, int64_t rows, int D, const v
   hipStream_t st = (hipStream_t)stream;
   const DropCfg d = make_drop(p_, seed);
   const unsigned grid = (unsigned)((rows + 3) / 4 > 8192 ? 8192 : (rows + 3) / 4);
+  const int vn = dtype == MDT_BF16 ? 8 : 4;
+  if (D % vn == 0 && ldx % vn == 0 && ldy % vn == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    if (dtype == MDT_F32) hipLaunchKernelGGL((dropout_vec_kernel<float, 4>), grid, 256, 0, st, rows, D, (const float*)x, ldx, (float*)y, ldy, d);
+    else if (dtype == MDT_BF16) hipLaunchKernelGGL((dropout_vec_kernel<bf16_t, 8>), grid, 256, 0, st, rows, D, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, d);
+    else MDT_UNSUPPORTED("mdt_dropout: dtype %d", dtype);
+    return check_launch("dropout_vec");
+  }
   if (dtype == MDT_F32) hipLaunchKernelGGL((dropout_kernel<float>), grid, 256, 0, st, rows, D, (const float*)x, ldx, (float*)y, ldy, d);
   else if (dtype == MDT_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), grid, 256, 0, st, rows, D, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, d);
   else MDT_UNSUPPORTED("mdt_dropout: dtype %d", dtype);

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
       const int c = (i * 64 + lane) * VN;
       if (c < D) {
         Vec<T> o, od, a;
+        float ds0 = 0.f, ds1 = 0.f;
         if (add) a = *(const Vec<T>*)(add + row * ldadd + c);
 #pragma unroll
         for (int j = 0; j < VN; ++j) {
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
           o.set(j, v);
           if constexpr (TAIL) {
             if (dxd) {   // second output: the gradient of the dense layer behind a hidden dropout
-              v = o.get(j) * drop_scale(drop, (uint64_t)row * D + c + j);
+              if ((j & 1) == 0) drop_scale2(drop, (uint64_t)row * D + c + j, ds0, ds1);   // D and c are even
+              v = o.get(j) * ((j & 1) ? ds1 : ds0);
               od.set(j, v);
               v = od.get(j);
             } else {
