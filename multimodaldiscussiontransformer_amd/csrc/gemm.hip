@@ -294,6 +294,108 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
   }
 }
 
+// Register-resident epilogue of the bf16-output ping-pong kernel.  The main loop issues the MFMAs with the
+// operands swapped (weights as A, activations as B), so a lane's accumulator acc[i][j] holds ONE output row
+// (m = 16 i + (lane & 15)) and four consecutive columns (n = 16 j + 4 (lane >> 4) + r).  One
+// v_permlane16_swap per register between the column tiles j and j + 1 turns that into eight consecutive
+// columns per lane (odd 16-lane rows of tile j trade places with even rows of tile j + 1), so bias, saved
+// pre-activation, residual and output all move as 16-byte vectors covering 64 contiguous bytes of 16 rows
+// per wave instruction — no LDS parking, no workgroup barrier, and no wave waits for another one.
+__device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc)[8][4], int lane, int64_t m0w, int64_t n0w) {
+  const int c = lane & 15, g = lane >> 4;
+  const int ep = p.epilogue;
+  int64_t gcs[2];
+  float bias[2][8];
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) {
+    gcs[jp] = n0w + 32 * jp + 16 * (g & 1) + 8 * (g >> 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[jp][e] = 0.f;
+    if (ep & MDT_EPI_BIAS) {
+      const bf16x8 b = *(const bf16x8*)((const bf16_t*)p.bias + gcs[jp]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bias[jp][e] = (float)b[e];
+    }
+  }
+  float cs[2][8];
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[jp][e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t gr = m0w + 16 * i + c;
+    const bool live = gr < p.M;
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, acc[i][2 * jp][r]),
+                                                         __builtin_bit_cast(unsigned, acc[i][2 * jp + 1][r]), false, false);
+        v[r] = __builtin_bit_cast(float, (unsigned)sw[0]);
+        v[4 + r] = __builtin_bit_cast(float, (unsigned)sw[1]);
+      }
+      if (!live) continue;
+      const int64_t gc = gcs[jp];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[jp][e];
+      if (ep & MDT_EPI_GELU) {
+        if (p.aux) {
+          bf16x8 u;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { u[e] = (bf16_t)v[e]; v[e] = (float)u[e]; }  // backward differentiates at the stored value
+          *(bf16x8*)((bf16_t*)p.aux + gr * p.ldaux + gc) = u;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+      }
+      if (ep & MDT_EPI_DROPOUT) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          float s0, s1;
+          drop_scale2(p.drop, (uint64_t)gr * p.N + gc + e, s0, s1);
+          v[e] *= s0;
+          v[e + 1] *= s1;
+        }
+      }
+      if (ep & MDT_EPI_DGELU) {
+        const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + gr * p.ldaux + gc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_fast_grad((float)u[e]);
+      }
+      if (ep & MDT_EPI_RESIDUAL) {
+        const bf16x8 r = *(const bf16x8*)((const bf16_t*)p.residual + gr * p.ldr + gc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+      }
+      if (ep & MDT_EPI_COLSUM) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[jp][e] += v[e];
+      }
+      bf16_t* cptr = (bf16_t*)p.C + gr * p.ldc + gc;
+      if (ep & MDT_EPI_ACCUM) {
+        const bf16x8 o = *(const bf16x8*)cptr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)o[e];
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+      *(bf16x8*)cptr = o;
+    }
+  }
+  if (ep & MDT_EPI_COLSUM) {   // the 16 lanes of a row group hold 16 rows of the same columns
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float s_ = row16_sum(cs[jp][e]);
+        if (c == 0) atomicAdd(p.colsum + gcs[jp] + e, s_);
+      }
+  }
+}
+
 template <typename TOut, bool A_KM, bool B_KM>
 __global__ __launch_bounds__(256) void gemm_bf16_tile128(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (A 16K + B 16K)
@@ -481,6 +583,7 @@ template <typename TOut, bool A_KM, bool B_KM, int PHASES>
 __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
   constexpr int BM = 256, BN = 256;
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr bool SWAP = sizeof(TOut) == 2;   // bf16 output: transposed accumulators + direct_epilogue
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -556,7 +659,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[mh * 4 + i][j] = mfma_bf16(a[i], b[j], acc[mh * 4 + i][j]);
+          for (int j = 0; j < 4; ++j)
+            acc[mh * 4 + i][j] = SWAP ? mfma_bf16(b[j], a[i], acc[mh * 4 + i][j]) : mfma_bf16(a[i], b[j], acc[mh * 4 + i][j]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -581,7 +685,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(a[i], b[j], acc[i][j]);
+          for (int j = 0; j < 4; ++j) acc[i][j] = SWAP ? mfma_bf16(b[j], a[i], acc[i][j]) : mfma_bf16(a[i], b[j], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -590,6 +694,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
     }
   }
   if (!late) __builtin_amdgcn_s_barrier();     // equalise the barrier count of the two groups
+  if constexpr (SWAP) {
+    direct_epilogue(p, acc, lane, m0 + wr * 128, n0 + wc * 64);
+    return;
+  }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     f32x4 blk[4][4];
@@ -811,6 +919,7 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   p.M = M; p.N = N; p.K = K; p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
   p.epilogue = epilogue; p.alpha = alpha; p.bias = bias; p.residual = residual; p.ldr = ldr;
   p.aux = aux; p.ldaux = ldaux; p.split_k = split_k;
+  MDT_CHECK_ARG(!(epilogue & MDT_EPI_DROPOUT) || M * N < DROP_MAX_ELEMS, "mdt_gemm: dropout site of %lld elements (limit 2^33)", (long long)(M * N));
   p.drop = make_drop((epilogue & MDT_EPI_DROPOUT) ? drop_p : 0.f, drop_seed);
   p.colsum = colsum;
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_COLSUM) || (colsum && split_k == 1), "mdt_gemm: MDT_EPI_COLSUM needs a colsum buffer and split_k == 1");
@@ -909,6 +1018,7 @@ extern "C" int mdt_dropout(void* stream, int dtype, int64_t rows, int D, const v
   if (rows == 0 || D == 0) return MDT_OK;
   MDT_CHECK_ARG(x && y && p_ >= 0.f && p_ < 1.f, "mdt_dropout: bad arguments (p=%f)", p_);
   hipStream_t st = (hipStream_t)stream;
+  MDT_CHECK_ARG(rows * D < DROP_MAX_ELEMS, "mdt_dropout: site of %lld elements (limit 2^33)", (long long)(rows * D));
   const DropCfg d = make_drop(p_, seed);
   const unsigned grid = (unsigned)((rows + 3) / 4 > 8192 ? 8192 : (rows + 3) / 4);
   const int vn = dtype == MDT_BF16 ? 8 : 4;
@@ -926,7 +1036,7 @@ extern "C" int mdt_dropout(void* stream, int dtype, int64_t rows, int D, const v
 
 extern "C" int mdt_dropout_mask(void* stream, int64_t n, float p_, uint64_t seed, uint8_t* mask) {
   if (n == 0) return MDT_OK;
-  MDT_CHECK_ARG(mask && p_ >= 0.f && p_ < 1.f, "mdt_dropout_mask: bad arguments");
+  MDT_CHECK_ARG(mask && p_ >= 0.f && p_ < 1.f && n < DROP_MAX_ELEMS, "mdt_dropout_mask: bad arguments");
   hipLaunchKernelGGL(dropout_mask_kernel, (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256), 256, 0,
                      (hipStream_t)stream, n, make_drop(p_, seed), mask);
   return check_launch("dropout_mask");

@@ -262,6 +262,7 @@ extern "C" int mdt_layernorm_bwd(void* stream, int dtype, int64_t rows, int D, c
                                  void* dxd, int64_t lddxd, float drop_p, uint64_t drop_seed, float* colsum) {
   if (rows == 0) return MDT_OK;
   MDT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "layernorm_bwd: dropout p=%f out of [0,1)", drop_p);
+  MDT_CHECK_ARG(!dxd || rows * D < DROP_MAX_ELEMS, "layernorm_bwd: dropout site of %lld elements (limit 2^33)", (long long)(rows * D));
   const DropCfg drop = make_drop(dxd ? drop_p : 0.f, drop_seed);
   MDT_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
   if (int e = ln_check(dtype, D, lddy, ldx, dy, x)) return e;

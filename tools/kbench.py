@@ -26,15 +26,10 @@ def main():
     bf = torch.bfloat16
     M = 212992
     import os
-    for force, ph in (("pp", "4"), ("pp", "2")):
-        os.environ["MDT_GEMM_PP_PHASES"] = ph
-        if force is None:
-            os.environ.pop("MDT_GEMM_TILE", None)
-        else:
-            os.environ["MDT_GEMM_TILE"] = force
-        print(f"== GEMM bf16, tile = {force or 'auto'}, phases = {ph} ==")
-        gemm_section(M, dev, bf)
-    rest(M, dev, bf)
+    print("== GEMM bf16 (default dispatch) ==")
+    gemm_section(M, dev, bf)
+    if "--gemm-only" not in sys.argv:
+        rest(M, dev, bf)
 
 
 def gemm_section(M, dev, bf):
@@ -64,7 +59,16 @@ def gemm_section(M, dev, bf):
     bias = torch.randn(3072, device=dev, dtype=bf); aux = torch.empty(M, 3072, device=dev, dtype=bf)
     out = torch.empty(M, 3072, device=dev, dtype=bf)
     t = timeit(lambda: ops.gemm(a, b, bias=bias, aux=aux, out=out, epilogue=ops.EPI_GELU))
-    print(f"ffn1 gelu: {t*1e3:8.3f} ms {2*M*3072*768/t/1e12:7.1f} TF/s")
+    print(f"ffn1 gelu+aux: {t*1e3:8.3f} ms {2*M*3072*768/t/1e12:7.1f} TF/s")
+    t = timeit(lambda: ops.gemm(a, b, bias=bias, aux=aux, out=out, epilogue=ops.EPI_GELU | ops.EPI_DROPOUT, drop_p=0.3, drop_seed=5))
+    print(f"ffn1 gelu+aux+dropout: {t*1e3:8.3f} ms {2*M*3072*768/t/1e12:7.1f} TF/s")
+    dy = torch.randn(M, 768, device=dev, dtype=bf); w2 = torch.randn(768, 3072, device=dev, dtype=bf)
+    t = timeit(lambda: ops.gemm(dy, w2, trans_b=True, aux=aux, out=out, epilogue=ops.EPI_DGELU | ops.EPI_DROPOUT, drop_p=0.3, drop_seed=5))
+    print(f"ffn2 dgrad dgelu+dropout: {t*1e3:8.3f} ms {2*M*3072*768/t/1e12:7.1f} TF/s")
+    res = torch.randn(M, 768, device=dev, dtype=bf); w3 = torch.randn(768, 3072, device=dev, dtype=bf); b3 = torch.randn(768, device=dev, dtype=bf)
+    o3 = torch.empty(M, 768, device=dev, dtype=bf)
+    t = timeit(lambda: ops.gemm(out, w3, bias=b3, residual=res, out=o3, epilogue=ops.EPI_DROPOUT, drop_p=0.4, drop_seed=5))
+    print(f"ffn2 fwd bias+dropout+residual: {t*1e3:8.3f} ms {2*M*3072*768/t/1e12:7.1f} TF/s")
     del a, b, bias, aux, out
 
 
