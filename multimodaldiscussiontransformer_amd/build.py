@@ -11,6 +11,9 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmdt_hip.so")
 SOURCES = ["gemm.hip", "layernorm.hip", "attention.hip", "attention_v2.hip", "rowops.hip", "optim.hip", "host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-ffp-contract=off"]
+# attention: keep MFMA results in VGPRs — the softmax works on the accumulators in place, and with the default
+# AGPR form the compiler spends 10-15 % of the VALU stream on v_accvgpr_read/write copies (gfx950's file is unified)
+EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "attention_v2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _stale(target, deps):
@@ -33,7 +36,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
             lang = ["-x", "hip"] if s.endswith(".cpp") else []
-            jobs.append([hipcc] + FLAGS + lang + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + EXTRA.get(s, []) + lang + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

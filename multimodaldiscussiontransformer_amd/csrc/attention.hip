@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
         a.lse[((int64_t)seq * a.H + h) * S + q] = (sum[r] > 0.f) ? mx[r] + __logf(sum[r]) : -INFINITY;
       sum[r] = (sum[r] > 0.f) ? 1.0f / sum[r] : 0.f;
     }
-    const uint32_t drop_base = (uint32_t)((seq * a.H + h) * S) * (uint32_t)S;   // host guarantees nseq*H*S*S < 2^32
+    const int drop_bh = seq * a.H + h;   // counters: attention_common.hpp
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
         float pv = sc[t][r] * sum[r];
         if constexpr (DROP) {
           const int q = q0 + (lane >> 4) * 4 + r, key = t * 16 + (lane & 15);
-          pv *= drop_scale(P.drop, (uint64_t)(drop_base + (uint32_t)(q * S + key)));
+          pv *= attn_drop_scale(P.drop, drop_bh, S, q, key);
         }
         scratch[((lane >> 4) * 4 + r) * sld + t * 16 + (lane & 15)] = from_f32<T>(pv);
       }
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams P) {
   __syncthreads();
 
   BiasCtx bc{seq, h, S, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
-  const uint32_t drop_base = (uint32_t)((seq * a.H + h) * S) * (uint32_t)S;   // host guarantees nseq*H*S*S < 2^32
+  const int drop_bh = seq * a.H + h;   // counters: attention_common.hpp
   const Src<T> gQ{qkv, tld, S};
   const Src<T> gDO{dout, dld, S};
   const int n_t = (S + 15) >> 4;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams P) {
           const float l = s_lse[q];
           const float p = (v == -INFINITY || l == -INFINITY || !qok) ? 0.f : __expf(v - l);
           sc[t][r] = p;
-          if constexpr (DROP) dp[t][r] *= drop_scale(P.drop, (uint64_t)(drop_base + (uint32_t)(q * S + key)));   // dP = dD * M / (1-p)
+          if constexpr (DROP) dp[t][r] *= attn_drop_scale(P.drop, drop_bh, S, q, key);   // dP = dD * M / (1-p)
           del[r] += p * dp[t][r];
         }
       }
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams P) {
           float ds = dp[t][r];
           float pd = p;
           if constexpr (DROP) {
-            const float m = drop_scale(P.drop, (uint64_t)(drop_base + (uint32_t)(qc * S + key)));
+            const float m = attn_drop_scale(P.drop, drop_bh, S, qc, key);
             ds *= m;                          // dP^T = dD^T * M / (1-p)
             pd *= m;                          // D^T  = P^T * M / (1-p)
           }
@@ -565,15 +565,17 @@ static int dispatch(hipStream_t st, const AttnParams& p) {
   const mdt_attn_fwd_args& a = p.f;
   const bool st_bias = a.attn_bias != nullptr;
   if (a.dtype == MDT_BF16) {
-    if (a.hd == 64 && getenv("MDT_ATTN_V1") == nullptr) {
+    // a plain dense bias (no structural terms) is only handled by the kernels in this file
+    const bool dense_only = (a.dense_bias != nullptr || p.d_dense_bias != nullptr) && !st_bias;
+    if (a.hd == 64 && !dense_only && getenv("MDT_ATTN_V1") == nullptr) {
       if (!BWD) return attention_v2_dispatch(st, p, false);              // forward: register-resident P
       // backward, measured at C2 shapes (profiles/round1_attention_v2.txt): S <= 112 -> whole-row v2,
       // longer sequences -> chunked v3; tiny graphs (S <= 80) stay on the LDS-scratch kernel below
       const char* force = getenv("MDT_ATTN_BWD");      // "v1" | "v2" | "v3" for A/B runs
-      const bool drop = a.drop_p > 0.f;                // with dropout the whole-row v2 falls to 1 wave / SIMD
+      const bool drop = a.drop_p > 0.f;                // with dropout the whole-row v2 falls to 1 wave / SIMD: chunked v3 wins
       if (BWD && a.S > 256 && !force) return attention_v3_bwd_dispatch(st, p);   // ViT-L/14: 4 + 257 tokens
-      const bool v1 = force ? !strcmp(force, "v1") : (a.S <= 80 || (drop && a.S <= 112));
-      const bool v2 = force ? !strcmp(force, "v2") : (!drop && a.S <= 112);
+      const bool v1 = force ? !strcmp(force, "v1") : a.S <= 80;
+      const bool v2 = (force ? !strcmp(force, "v2") : !drop) && a.S <= 112;
       if (!v1) return v2 ? attention_v2_dispatch(st, p, true) : attention_v3_bwd_dispatch(st, p);
     }
     if (a.hd == 64) return st_bias ? dispatch_nt<bf16_t, 64, true, BWD>(st, p) : dispatch_nt<bf16_t, 64, false, BWD>(st, p);
@@ -596,8 +598,8 @@ static int check_args(const mdt_attn_fwd_args& a) {
     MDT_CHECK_ARG(a.ld_qkv % 8 == 0 && ((uintptr_t)a.qkv & 15) == 0, "attention(bf16): qkv must be 16-byte aligned rows");
   if (a.attn_bias) MDT_CHECK_ARG(a.spatial_pos && a.sp_table && a.virt && a.num_spatial > 0, "attention: incomplete structural bias");
   MDT_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f, "attention: dropout p=%f out of [0,1)", a.drop_p);
-  MDT_CHECK_ARG(a.drop_p == 0.f || (uint64_t)a.nseq * a.H * a.S * a.S < (1ull << 32),
-                "attention: dropout counters are 32-bit (nseq*H*S*S must stay below 2^32)");
+  MDT_CHECK_ARG(a.drop_p == 0.f || (uint64_t)a.nseq * a.H * a.S * (a.S + 1) < (1ull << 32),
+                "attention: dropout counters are 32-bit (nseq*H*S*(S+1) must stay below 2^32)");
   return MDT_OK;
 }
 

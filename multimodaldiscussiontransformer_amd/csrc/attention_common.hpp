@@ -48,6 +48,24 @@ __device__ __forceinline__ float pair_bias(const BiasCtx& b, int q, int key) {
   return v;
 }
 
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
+// Attention-probability dropout counters: element (bh, q, key) -> (bh*S + q)*S2 + key with S2 = S rounded
+// up to even, so keys 2i and 2i+1 of one query share a 32-bit word of the mixer (common.hpp "dropout RNG").
+__device__ __forceinline__ uint32_t attn_row_pairs(int bh, int S, int q) {
+  return (uint32_t)(bh * S + q) * (uint32_t)((S + 1) >> 1);
+}
+__device__ __forceinline__ uint32_t attn_drop_word(const DropCfg& d, uint32_t row_pairs, int key) {
+  return drop_mix((row_pairs + (uint32_t)(key >> 1)) ^ d.key);
+}
+__device__ __forceinline__ bool drop_keep_lo(const DropCfg& d, uint32_t w) { return (w & 0xFFFFu) >= d.thresh; }
+__device__ __forceinline__ bool drop_keep_hi(const DropCfg& d, uint32_t w) { return (w >> 16) >= d.thresh; }
+// generic (one element): the same decision as the word helpers above
+__device__ __forceinline__ float attn_drop_scale(const DropCfg& d, int bh, int S, int q, int key) {
+  const uint32_t w = attn_drop_word(d, attn_row_pairs(bh, S, q), key);
+  return ((key & 1) ? drop_keep_hi(d, w) : drop_keep_lo(d, w)) ? d.inv_keep : 0.f;
+}
+
 int attention_v2_dispatch(hipStream_t st, const AttnParams& p, bool bwd);
 int attention_v3_bwd_dispatch(hipStream_t st, const AttnParams& p);
 

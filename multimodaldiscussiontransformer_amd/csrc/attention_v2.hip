@@ -15,7 +15,6 @@
 // and reduces the softmax reductions from four shuffles to two.
 // Same C ABI, same masks / structural bias / dropout semantics; attention.hip keeps the fp32
 // parity path and remains selectable for bf16 with MDT_ATTN_V1=1.
-#define MDT_ATTN_V2_BWD 1   // built; selected at run time with MDT_ATTN_V2_BWD=1 (default backward: attention.hip)
 #include "attention_common.hpp"
 
 namespace mdt {
@@ -67,6 +66,11 @@ __device__ __forceinline__ float col_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------- forward
+// Softmax in the exp2 domain (scores and key bias pre-multiplied by log2 e: v_exp_f32 is exp2), masked keys
+// carry -inf so no element needs a compare; the probabilities stay UNNORMALISED (e <= 1) through P.V and the
+// 16 output values of a lane are scaled by 1 / sum (and 1 / (1 - p)) at the end; dropout decides two
+// neighbouring keys per mixer word.  Kernels without structural bias take no per-pair bias at all — a plain
+// dense bias is served by attention.hip (see the dispatch there).
 template <int HD, int NT, bool STRUCT, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(AttnParams P) {
   constexpr int ND = HD / 16, NP = (NT + 1) / 2, S_PAD = NP * 32;
@@ -86,7 +90,8 @@ __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(AttnParams P) {
   v2_stage<HD>(imgV, qkv + 2 * D, tld, S, S_PAD, tid);
   for (int i = tid; i < S_PAD; i += 256) s_kb[i] = key_only_bias<bf16_t>(bc, i);
   __syncthreads();
-  const uint32_t drop_base = (uint32_t)((seq * a.H + h) * S) * (uint32_t)S;
+  const int drop_bh = seq * a.H + h;   // counters: attention_common.hpp
+  const float scale2 = a.scale * LOG2E;
   const int g = lane >> 4, c = lane & 15;
   const int n_qt = (S + 15) >> 4;
   for (int qt = wave; qt < n_qt; qt += 4) {
@@ -108,36 +113,45 @@ __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(AttnParams P) {
       }
     float mx = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      const f32x4 kb = *(const f32x4*)(s_kb + t * 16 + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = t * 16 + 4 * g + r;
-        float v = sc[t][r] * a.scale + s_kb[key];
-        if ((a.dense_bias || STRUCT) && key < S) v += pair_bias<bf16_t, STRUCT>(bc, qc, key);
+        float v = __builtin_fmaf(sc[t][r], scale2, kb[r]);     // kb is 0 or -inf: no scaling needed
+        if constexpr (STRUCT) {
+          const int key = t * 16 + 4 * g + r;
+          if (key < S) v = __builtin_fmaf(pair_bias<bf16_t, true>(bc, qc, key), LOG2E, v);
+        }
         sc[t][r] = v;
         mx = fmaxf(mx, v);
       }
+    }
     mx = col_max(mx);
+    const float mxc = (mx == -INFINITY) ? 0.f : mx;   // fully masked row: every exp2 below is exp2(-inf) = 0
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = (sc[t][r] == -INFINITY) ? 0.f : __expf(sc[t][r] - mx);
+        const float e = __builtin_amdgcn_exp2f(sc[t][r] - mxc);
         sc[t][r] = e;
         sum += e;
       }
     sum = col_sum(sum);
-    if (g == 0 && q < S) a.lse[((int64_t)seq * a.H + h) * S + q] = (sum > 0.f) ? mx + __logf(sum) : -INFINITY;
-    const float inv = (sum > 0.f) ? 1.0f / sum : 0.f;
+    if (g == 0 && q < S) a.lse[((int64_t)seq * a.H + h) * S + q] = (sum > 0.f) ? (mxc + __builtin_amdgcn_logf(sum)) * LN2 : -INFINITY;
+    float inv = (sum > 0.f) ? __builtin_amdgcn_rcpf(sum) : 0.f;
+    if constexpr (DROP) {
+      inv *= P.drop.inv_keep;
+      const uint32_t rp = attn_row_pairs(drop_bh, S, qc) + 2 * g;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float pv = sc[t][r] * inv;
-        if constexpr (DROP) pv *= drop_scale(P.drop, (uint64_t)(drop_base + (uint32_t)(q * S + t * 16 + 4 * g + r)));
-        sc[t][r] = pv;
+      for (int t = 0; t < NT; ++t) {
+        const uint32_t w0 = drop_mix((rp + 8 * t) ^ P.drop.key), w1 = drop_mix((rp + 8 * t + 1) ^ P.drop.key);
+        sc[t][0] = drop_keep_lo(P.drop, w0) ? sc[t][0] : 0.f;
+        sc[t][1] = drop_keep_hi(P.drop, w0) ? sc[t][1] : 0.f;
+        sc[t][2] = drop_keep_lo(P.drop, w1) ? sc[t][2] : 0.f;
+        sc[t][3] = drop_keep_hi(P.drop, w1) ? sc[t][3] : 0.f;
       }
+    }
     f32x4 o[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -152,17 +166,15 @@ __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(AttnParams P) {
       bf16_t* orow = (bf16_t*)a.out + (row0 + (int64_t)q * a.pos_stride) * a.ld_out + h * HD + 4 * g;
 #pragma unroll
       for (int d = 0; d < ND; ++d)
-        *(bf16x4*)(orow + d * 16) = bf16x4{(bf16_t)o[d][0], (bf16_t)o[d][1], (bf16_t)o[d][2], (bf16_t)o[d][3]};
+        *(bf16x4*)(orow + d * 16) = bf16x4{(bf16_t)(o[d][0] * inv), (bf16_t)(o[d][1] * inv), (bf16_t)(o[d][2] * inv), (bf16_t)(o[d][3] * inv)};
     }
   }
 }
 
 // ---------------------------------------------------------------------------- backward
-// Measured SLOWER than attention.hip's backward on gfx950 / ROCm 7.2 (two live accumulator sets
-// of NT tiles + packed operands push it to 1 wave per SIMD and, from NT = 9, into scratch):
-// BERT S=104 2.36 vs 1.50 ms, ViT S=201 2.24 vs 1.74 ms (profiles/round1_attention_v2.txt).  Kept
-// for reference, built only with -DMDT_ATTN_V2_BWD; the default backward stays attention.hip.
-#ifdef MDT_ATTN_V2_BWD
+// Whole-row backward: two live accumulator sets of NT tiles + packed operands, so it only pays up to
+// NT = 7 (S <= 112; beyond that it drops to 1 wave per SIMD and spills) — longer rows take the chunked
+// v3 kernel below (profiles/round1_attention_v2.txt).
 template <int HD, int NT, bool STRUCT, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
   constexpr int ND = HD / 16, NP = (NT + 1) / 2, S_PAD = NP * 32;
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
   }
   for (int i = tid; i < nhist; i += 256) s_hist[i] = 0.f;
   __syncthreads();
-  const uint32_t drop_base = (uint32_t)((seq * a.H + h) * S) * (uint32_t)S;
+  const int drop_bh = seq * a.H + h;   // counters: attention_common.hpp
   const int g = lane >> 4, c = lane & 15;
   const int n_t = (S + 15) >> 4;
 
@@ -228,10 +240,10 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
       for (int r = 0; r < 4; ++r) {
         const int key = t * 16 + 4 * g + r;
         float v = sc[t][r] * a.scale + s_kb[key];
-        if ((a.dense_bias || STRUCT) && key < S) v += pair_bias<bf16_t, STRUCT>(bc, qc, key);
+        if (STRUCT && key < S) v += pair_bias<bf16_t, STRUCT>(bc, qc, key);
         const float p = (v == -INFINITY || l == -INFINITY || !qok) ? 0.f : __expf(v - l);
         sc[t][r] = p;
-        if constexpr (DROP) dp[t][r] *= drop_scale(P.drop, (uint64_t)(drop_base + (uint32_t)(q * S + key)));
+        if constexpr (DROP) dp[t][r] *= attn_drop_scale(P.drop, drop_bh, S, q, key);
         del += p * dp[t][r];
       }
     del = col_sum(del);
@@ -321,13 +333,13 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
         const bool qok = q < S;
         const int qc = qok ? q : S - 1;
         float v = sc[t][r] * a.scale + kb;
-        if ((a.dense_bias || STRUCT) && kok) v += pair_bias<bf16_t, STRUCT>(bc, qc, key);
+        if (STRUCT && kok) v += pair_bias<bf16_t, STRUCT>(bc, qc, key);
         const float l = s_lse[q];
         const float p = (v == -INFINITY || l == -INFINITY || !qok || !kok) ? 0.f : __expf(v - l);
         float ds = dp[t][r];
         float pd = p;
         if constexpr (DROP) {
-          const float m = drop_scale(P.drop, (uint64_t)(drop_base + (uint32_t)(qc * S + key)));
+          const float m = attn_drop_scale(P.drop, drop_bh, S, qc, key);
           ds *= m;
           pd *= m;
         }
@@ -361,7 +373,6 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
   }
 }
 
-#endif  // MDT_ATTN_V2_BWD
 
 // ---------------------------------------------------------------------------- backward, chunked (v3)
 // With the forward log-sum-exp saved and delta = rowsum(dO * O) (valid with dropout too: O = D V),
@@ -396,6 +407,10 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
   BiasCtx bc{seq, h, S, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
   v2_stage<HD>(img0, qkv + D, tld, S, s_pad, tid);      // K
   v2_stage<HD>(img1, qkv + 2 * D, tld, S, s_pad, tid);  // V
+  // s_lse holds lse * log2(e) (+inf for rows without a finite lse, so every p of such a row is exp2(-inf) = 0);
+  // s_delta holds delta * (1 - p_drop): the 1 / (1 - p_drop) factor of the dropout mask is folded out of
+  // dS and dV and applied once to the outputs.
+  const float ik = DROP ? P.drop.inv_keep : 1.0f, rik = 1.0f / ik;
   for (int i = tid; i < s_pad; i += 256) {
     s_kb[i] = key_only_bias<bf16_t>(bc, i);
     float l = -INFINITY, de = 0.f;
@@ -409,17 +424,19 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
         for (int e = 0; e < 8; ++e) de += (float)o[e] * (float)g_[e];
       }
     }
-    s_lse[i] = l;
-    s_delta[i] = de;
+    s_lse[i] = (l == -INFINITY) ? INFINITY : l * LOG2E;
+    s_delta[i] = de * rik;
   }
   for (int i = tid; i < nhist; i += 256) s_hist[i] = 0.f;
   __syncthreads();
-  const uint32_t drop_base = (uint32_t)((seq * a.H + h) * S) * (uint32_t)S;
+  const int drop_bh = seq * a.H + h;   // counters: attention_common.hpp
+  const uint32_t s2h = (uint32_t)((S + 1) >> 1);
+  const float scale2 = a.scale * LOG2E;
   const int g = lane >> 4, c = lane & 15;
   const int n_t = (S + 15) >> 4;
   const int n_chunk = s_pad >> 6;           // 64-wide chunks (s_pad is a multiple of 64)
 
-  // ------------------------------------------------------------------ pass A
+  // ------------------------------------------------------------------ pass A (queries on lanes)
   for (int qt = wave; qt < n_t; qt += 4) {
     const int q0 = qt * 16;
     const int q = q0 + c;
@@ -431,7 +448,8 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
       fq[ks] = v2_frag_glb(qkv, tld, S, q0, ks * 32, lane);
       fo[ks] = v2_frag_glb(dout, dld, S, q0, ks * 32, lane);
     }
-    const float l = s_lse[qc], del = s_delta[qc];
+    const float l2 = s_lse[qc], del = s_delta[qc];
+    const uint32_t rp = attn_row_pairs(drop_bh, S, qc) + 2 * g;
     f32x4 dq[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -449,31 +467,41 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
           if (ks == HD / 32 - 1 && (t & 1)) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 kb = *(const f32x4*)(s_kb + (t0 + t) * 16 + 4 * g);
+        bool keep[4] = {true, true, true, true};
+        if constexpr (DROP) {
+          const uint32_t w0 = drop_mix((rp + 8 * (t0 + t)) ^ P.drop.key), w1 = drop_mix((rp + 8 * (t0 + t) + 1) ^ P.drop.key);
+          keep[0] = drop_keep_lo(P.drop, w0); keep[1] = drop_keep_hi(P.drop, w0);
+          keep[2] = drop_keep_lo(P.drop, w1); keep[3] = drop_keep_hi(P.drop, w1);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          float v = __builtin_fmaf(sc[t][r], scale2, kb[r]);
           const int key = (t0 + t) * 16 + 4 * g + r;
-          float v = sc[t][r] * a.scale + s_kb[key];
-          if ((a.dense_bias || STRUCT) && key < S) v += pair_bias<bf16_t, STRUCT>(bc, qc, key);
-          const float p = (v == -INFINITY || l == -INFINITY || !qok) ? 0.f : __expf(v - l);
-          float dpe = dp[t][r];
-          if constexpr (DROP) dpe *= drop_scale(P.drop, (uint64_t)(drop_base + (uint32_t)(q * S + key)));
-          const float ds = p * (dpe - del);
+          if constexpr (STRUCT) {
+            if (key < S) v = __builtin_fmaf(pair_bias<bf16_t, true>(bc, qc, key), LOG2E, v);
+          }
+          const float p = __builtin_amdgcn_exp2f(v - l2);
+          const float dpe = keep[r] ? dp[t][r] : 0.f;
+          const float ds = p * (dpe - del);           // true dS = ds / (1 - p_drop)
           sc[t][r] = ds;
-          if (qok && key < S) {
-            if (P.d_dense_bias) P.d_dense_bias[(((int64_t)seq * a.H + h) * S + q) * S + key] = ds;
-            if constexpr (STRUCT) {
-              if (P.d_sp_table && ds != 0.f) {
+          if constexpr (STRUCT) {
+            if (qok && key < S) {
+              const float dst = ds * ik;
+              if (P.d_dense_bias) P.d_dense_bias[(((int64_t)seq * a.H + h) * S + q) * S + key] = dst;
+              if (P.d_sp_table && dst != 0.f) {
                 if (q >= 1 && key >= 1) {
                   const int idx = a.spatial_pos[((int64_t)seq * (S - 1) + (q - 1)) * (S - 1) + (key - 1)];
-                  if (idx != 0) atomicAdd(s_hist + idx, ds);
+                  if (idx != 0) atomicAdd(s_hist + idx, dst);
                 } else {
-                  atomicAdd(s_hist + a.num_spatial, ds);
+                  atomicAdd(s_hist + a.num_spatial, dst);
                 }
               }
             }
           }
         }
+      }
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {
         const bf16x8 fs = v2_pack(sc[2 * pi], sc[2 * pi + 1]);
@@ -483,11 +511,11 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
       }
     }
     if (qok) {
+      const float os = a.scale * ik;
       bf16_t* orow = dqkv + (int64_t)q * gld + 4 * g;
 #pragma unroll
       for (int d = 0; d < ND; ++d)
-        *(bf16x4*)(orow + d * 16) = bf16x4{(bf16_t)(dq[d][0] * a.scale), (bf16_t)(dq[d][1] * a.scale),
-                                           (bf16_t)(dq[d][2] * a.scale), (bf16_t)(dq[d][3] * a.scale)};
+        *(bf16x4*)(orow + d * 16) = bf16x4{(bf16_t)(dq[d][0] * os), (bf16_t)(dq[d][1] * os), (bf16_t)(dq[d][2] * os), (bf16_t)(dq[d][3] * os)};
     }
   }
   __syncthreads();   // K / V images are free
@@ -505,7 +533,12 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
     }
   }
   __syncthreads();
-  // ------------------------------------------------------------------ pass B
+  // ------------------------------------------------------------------ pass B (keys on lanes)
+  // A lane holds four consecutive QUERIES of one key, so its four dropout decisions sit in four different mixer
+  // words; the neighbouring lane (key ^ 1) needs the same four words (other half), so each lane of the pair
+  // computes two of them and they trade through one DPP quad swap each.
+  const int odd = c & 1;
+  const uint32_t base_rp = (uint32_t)(drop_bh * S) * s2h;
   for (int kt = wave; kt < n_t; kt += 4) {
     const int key0 = kt * 16;
     const int key = key0 + c;
@@ -517,6 +550,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
       fk[ks] = v2_frag_glb(qkv + D, tld, S, key0, ks * 32, lane);
       fv[ks] = v2_frag_glb(qkv + 2 * D, tld, S, key0, ks * 32, lane);
     }
+    const uint32_t kh = base_rp + (uint32_t)(key >> 1);
     f32x4 dv[ND], dk[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) { dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -534,26 +568,33 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
           if (ks == HD / 32 - 1 && (t & 1)) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) {
+        const int qb = (t0 + t) * 16 + 4 * g;
+        const f32x4 l2v = *(const f32x4*)(s_lse + qb);
+        const f32x4 dlv = *(const f32x4*)(s_delta + qb);
+        bool keep[4] = {true, true, true, true};
+        if constexpr (DROP) {
+          const uint32_t ra = kh + (uint32_t)(qb + 2 * odd) * s2h;
+          const uint32_t wa = drop_mix(ra ^ P.drop.key), wb = drop_mix((ra + s2h) ^ P.drop.key);
+          const uint32_t pa = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wa, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+          const uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wb, 0xB1, 0xF, 0xF, false);
+          const uint32_t w[4] = {odd ? pa : wa, odd ? pb : wb, odd ? wa : pa, odd ? wb : pb};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) keep[r] = ((w[r] >> (16 * odd)) & 0xFFFFu) >= P.drop.thresh;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int q = (t0 + t) * 16 + 4 * g + r;
-          const bool qok = q < S;
-          const int qc = qok ? q : S - 1;
-          float v = sc[t][r] * a.scale + kb;
-          if ((a.dense_bias || STRUCT) && kok) v += pair_bias<bf16_t, STRUCT>(bc, qc, key);
-          const float l = s_lse[q];
-          const float p = (v == -INFINITY || l == -INFINITY || !qok || !kok) ? 0.f : __expf(v - l);
-          float ds = dp[t][r];
-          float pd = p;
-          if constexpr (DROP) {
-            const float m = drop_scale(P.drop, (uint64_t)(drop_base + (uint32_t)(qc * S + key)));
-            ds *= m;
-            pd *= m;
+          float v = __builtin_fmaf(sc[t][r], scale2, kb);
+          if constexpr (STRUCT) {
+            const int q = qb + r;
+            if (kok && q < S) v = __builtin_fmaf(pair_bias<bf16_t, true>(bc, q, key), LOG2E, v);
           }
-          sc[t][r] = pd;
-          dp[t][r] = p * (ds - s_delta[q]);
+          const float p = __builtin_amdgcn_exp2f(v - l2v[r]);
+          const float dpv = keep[r] ? dp[t][r] : 0.f;
+          sc[t][r] = keep[r] ? p : 0.f;
+          dp[t][r] = p * (dpv - dlv[r]);
         }
+      }
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {
         const bf16x8 fp = v2_pack(sc[2 * pi], sc[2 * pi + 1]);
@@ -567,13 +608,13 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
       }
     }
     if (kok) {
+      const float os = a.scale * ik;
       bf16_t* krow = dqkv + (int64_t)key * gld + D + 4 * g;
       bf16_t* vrow = dqkv + (int64_t)key * gld + 2 * D + 4 * g;
 #pragma unroll
       for (int d = 0; d < ND; ++d) {
-        *(bf16x4*)(krow + d * 16) = bf16x4{(bf16_t)(dk[d][0] * a.scale), (bf16_t)(dk[d][1] * a.scale),
-                                           (bf16_t)(dk[d][2] * a.scale), (bf16_t)(dk[d][3] * a.scale)};
-        *(bf16x4*)(vrow + d * 16) = bf16x4{(bf16_t)dv[d][0], (bf16_t)dv[d][1], (bf16_t)dv[d][2], (bf16_t)dv[d][3]};
+        *(bf16x4*)(krow + d * 16) = bf16x4{(bf16_t)(dk[d][0] * os), (bf16_t)(dk[d][1] * os), (bf16_t)(dk[d][2] * os), (bf16_t)(dk[d][3] * os)};
+        *(bf16x4*)(vrow + d * 16) = bf16x4{(bf16_t)(dv[d][0] * ik), (bf16_t)(dv[d][1] * ik), (bf16_t)(dv[d][2] * ik), (bf16_t)(dv[d][3] * ik)};
       }
     }
   }
@@ -610,25 +651,25 @@ static int launch_v2(hipStream_t st, const AttnParams& p) {
   constexpr int S_PAD = ((NT + 1) / 2) * 32;
   const int nhist = (STRUCT && BWD) ? ((p.f.num_spatial + 1 + 3) & ~3) : 0;
   const size_t lds = (size_t)2 * S_PAD * V2_LD * 2 + (size_t)(BWD ? 3 : 1) * S_PAD * 4 + (size_t)nhist * 4;
-#ifdef MDT_ATTN_V2_BWD
-  const void* kern = BWD ? (const void*)attn_bwd_v2_kernel<64, NT, STRUCT, DROP> : (const void*)attn_fwd_v2_kernel<64, NT, STRUCT, DROP>;
-#else
-  if (BWD) { set_error("attention_v2: backward not built (MDT_ATTN_V2_BWD)"); return MDT_ERR_UNSUPPORTED; }
-  const void* kern = (const void*)attn_fwd_v2_kernel<64, NT, STRUCT, DROP>;
-#endif
-  if (lds > 64 * 1024) {
-    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      (void)hipGetLastError();
-      set_error("attention_v2: cannot reserve %zu bytes of LDS", lds);
-      return MDT_ERR_LAUNCH;
+  if constexpr (BWD && NT > 7) {
+    // the whole-row backward runs out of registers past 112 keys; attention.hip routes those to the chunked v3
+    set_error("attention_v2: backward supports S <= 112 (got %d)", p.f.S);
+    return MDT_ERR_UNSUPPORTED;
+  } else {
+    const void* kern;
+    if constexpr (BWD) kern = (const void*)attn_bwd_v2_kernel<64, NT, STRUCT, DROP>;
+    else kern = (const void*)attn_fwd_v2_kernel<64, NT, STRUCT, DROP>;
+    if (lds > 64 * 1024) {
+      if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("attention_v2: cannot reserve %zu bytes of LDS", lds);
+        return MDT_ERR_LAUNCH;
+      }
     }
+    if constexpr (BWD) hipLaunchKernelGGL((attn_bwd_v2_kernel<64, NT, STRUCT, DROP>), dim3(p.f.H, p.f.nseq), 256, lds, st, p);
+    else hipLaunchKernelGGL((attn_fwd_v2_kernel<64, NT, STRUCT, DROP>), dim3(p.f.H, p.f.nseq), 256, lds, st, p);
+    return check_launch(BWD ? "attention_bwd_v2" : "attention_fwd_v2");
   }
-#ifdef MDT_ATTN_V2_BWD
-  if (BWD) hipLaunchKernelGGL((attn_bwd_v2_kernel<64, NT, STRUCT, DROP>), dim3(p.f.H, p.f.nseq), 256, lds, st, p);
-  else
-#endif
-    hipLaunchKernelGGL((attn_fwd_v2_kernel<64, NT, STRUCT, DROP>), dim3(p.f.H, p.f.nseq), 256, lds, st, p);
-  return check_launch(BWD ? "attention_bwd_v2" : "attention_fwd_v2");
 }
 
 template <bool STRUCT, bool DROP, bool BWD>

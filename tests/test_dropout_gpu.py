@@ -32,6 +32,12 @@ def mask(ops, shape, p, seed):
     return ops.dropout_mask(n, p, seed).view(*shape).float().cpu() / (1.0 - p)
 
 
+def attn_mask(ops, nseq, H, S, p, seed):
+    """Keep/scale mask of attention-probability dropout: counters run over rows of even length (csrc/attention_common.hpp)."""
+    S2 = S + (S & 1)
+    return mask(ops, (nseq, H, S, S2), p, seed)[..., :S].contiguous()
+
+
 def test_standalone_dropout_statistics_and_determinism(ops):
     x = torch.ones(4096, 256).cuda()
     for p in (0.1, 0.3, 0.4):
@@ -76,16 +82,18 @@ def test_gemm_epilogue_dropout(ops, dtype):
     torch.testing.assert_close(out.cpu(), x.grad, atol=2e-3, rtol=2e-3)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("nseq,S,H", [(3, 20, 2), (2, 104, 3)])
-def test_attention_dropout(ops, dtype, nseq, S, H):
+@pytest.mark.parametrize("dtype,bwd", [(torch.float32, None), (torch.bfloat16, None), (torch.bfloat16, "v1"), (torch.bfloat16, "v3")])
+@pytest.mark.parametrize("nseq,S,H", [(3, 20, 2), (2, 104, 3), (2, 201, 2)])
+def test_attention_dropout(ops, dtype, bwd, nseq, S, H, monkeypatch):
     hd, p, seed = 64, 0.3, 4242
+    if bwd:
+        monkeypatch.setenv("MDT_ATTN_BWD", bwd)   # every backward kernel family regenerates the forward's mask
     D = H * hd
     qkv = rnd(nseq, S, 3 * D, seed=7).to(dtype)
     dout = rnd(nseq, S, D, seed=8).to(dtype)
     km = torch.ones(nseq, S, dtype=torch.uint8)
     km[1, S - 3:] = 0
-    m = mask(ops, (nseq, H, S, S), p, seed)
+    m = attn_mask(ops, nseq, H, S, p, seed)
     qr = qkv.float().requires_grad_(True)
     q, k, v = qr.split(D, dim=-1)
     hv = lambda t: t.view(nseq, S, H, hd).transpose(1, 2)
@@ -130,7 +138,7 @@ def test_graphormer_layer_training_dropout_exact(ops, pre_ln):
     s_attn, s_o, s_act, s_f2 = [(base + C * k) & M63 for k in (1, 2, 3, 4)]
     W = {n: prm.detach().cpu().clone().requires_grad_(True) for n, prm in layer.named_parameters()}
     xr = x.detach().cpu().clone().requires_grad_(True)
-    m_attn = mask(ops, (B, H, T, T), pa, s_attn)
+    m_attn = attn_mask(ops, B, H, T, pa, s_attn)
     m_o = mask(ops, (T * B, D), pd, s_o).view(T, B, D)
     m_act = mask(ops, (T * B, Fg), pact, s_act).view(T, B, Fg)
     m_f2 = mask(ops, (T * B, D), pd, s_f2).view(T, B, D)
