@@ -14,6 +14,9 @@
 // Replaces the nn.Linear calls of the reference (see include/mdt_hip.h, mdt_gemm).
 #include <stdlib.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "common.hpp"
 
 namespace mdt {
@@ -28,8 +31,10 @@ struct GemmParams {
   void* aux; int64_t ldaux;
   int split_k; int64_t k_chunk;
   int tiles_m, tiles_n;
+  int group_n;                  // column tiles swept together before moving down the rows (ping-pong kernel's tile order)
   DropCfg drop;
   float* colsum;
+  unsigned long long* stamps;   // diagnostic (MDT_GEMM_STAMP=1): per workgroup {shader cycles, 100-MHz ticks, k-tiles} of the main loop
 };
 
 // ------------------------------------------------------------------ shared epilogue
@@ -173,6 +178,48 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int rc_base, i
     const bf16x4 lo = lds_read_tr16((const bf16_t*)(lds_tile + k_lo * RB + ((blk ^ swz_km(k_lo)) * 32) + pp * 8));
     const bf16x4 hi = lds_read_tr16((const bf16_t*)(lds_tile + k_hi * RB + ((blk ^ swz_km(k_hi)) * 32) + pp * 8));
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+}
+
+// ---- 32-k stage images of the ping-pong kernel ----------------------------------------------------------
+// k-contiguous operands: [ROWS][32 k] with 64-byte rows, a 1-KiB LDS-DMA piece = 16 rows, 16-byte chunk
+// XOR-swizzled by {0,2,3,1}[(row >> 2) & 3] (conflict-free ds_read_b128, checked for all four lane groups).
+// k-major operands: [32 k][ROWS] with 2*ROWS-byte rows, a piece = 1024 / (2*ROWS) k-rows, 32-byte blocks
+// swizzled by swz_km(k) as in the 64-k image (conflict-free ds_read_b64_tr_b16).
+__device__ __forceinline__ int swz_h(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+template <bool KM, int ROWS, int NW>
+__device__ __forceinline__ void stage_step(__amdgpu_buffer_rsrc_t rs, int64_t ld_bytes, int64_t k0, int col0,
+                                           char* lds_tile, int wave, int lane) {
+  constexpr int NPIECE = ROWS / 16;    // 1-KiB pieces per 32-k stage of one operand
+#pragma unroll
+  for (int i = 0; i < NPIECE / NW; ++i) {
+    const int piece = wave + i * NW;
+    unsigned voff;
+    if constexpr (!KM) {
+      const int row = piece * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ swz_h(row);
+      voff = (unsigned)(row * ld_bytes + (k0 + chunk * 8) * 2);
+    } else {
+      constexpr int C16 = ROWS / 8;        // 16-B chunks per k-row
+      constexpr int KPP = 64 / C16;        // k-rows per piece
+      const int k = piece * KPP + lane / C16;
+      const int c16 = lane % C16;
+      const int blk = (c16 >> 1) ^ swz_km(k);
+      voff = (unsigned)((k0 + k) * ld_bytes + (col0 + blk * 16 + (c16 & 1) * 8) * 2);
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_tile + piece * 1024), 16, voff, 0, 0, 0);
+  }
+}
+
+// fragment of a 16(row|col) x 32(k) block of a 32-k stage
+template <bool KM, int ROWS>
+__device__ __forceinline__ bf16x8 load_frag_h(const char* lds_tile, int rc_base, int lane) {
+  if constexpr (!KM) {
+    const int row = rc_base + (lane & 15);
+    return *(const bf16x8*)(lds_tile + row * 64 + (((lane >> 4) ^ swz_h(row)) * 16));
+  } else {
+    return load_frag<true, ROWS>(lds_tile, rc_base, 0, lane);
   }
 }
 
@@ -382,7 +429,13 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-      *(bf16x8*)cptr = o;
+      if (ep & (1 << 20)) continue;                       // diagnostic: no output store
+      if (ep & (1 << 21)) {                               // diagnostic: write-through, do not keep the line in L2
+        const i32x4 raw = __builtin_bit_cast(i32x4, o);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(cptr), "v"(raw) : "memory");
+      } else {
+        *(bf16x8*)cptr = o;
+      }
     }
   }
   if (ep & MDT_EPI_COLSUM) {   // the 16 lanes of a row group hold 16 rows of the same columns
@@ -566,23 +619,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_tile256(GemmParams p) {
   }
 }
 
-// ------------------------------------------------------------------ bf16 256x256x64, ping-pong
-// Same tile and staging as gemm_bf16_tile256<BN=256>, but the K-tile is cut into four phases of
-// 16 MFMAs (k-step x row-half of the wave's 128x64 block) and each phase into a READ segment
-// (ds_read of the phase's fragments, LDS-DMA issue of the next K-tile) and an MFMA segment,
-// separated by s_barrier.  Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one of
-// its two resident waves is in an MFMA segment while the other fetches operands: the matrix
-// pipe no longer idles while both waves wait for LDS (MI355X_MICROARCH.md "Two waves per SIMD").
-//   barrier pairing: early group's n-th barrier == late group's (n-1)-th.
-//   RAW: every wave drains its own LDS-DMA loads of tile kt+1 (vmcnt(0)) before the barrier that
-//        closes its READ segment 3 of tile kt; the first read of tile kt+1 by anyone follows the
-//        barrier that pairs those two.  WAR: the loads of tile kt+1 are issued in READ 0 of tile
-//        kt, after the barrier behind which the late group completed (lgkmcnt(0)) its last reads
-//        of tile kt-1.
-template <typename TOut, bool A_KM, bool B_KM, int PHASES>
+// ------------------------------------------------------------------ bf16 256x256, ping-pong over a ring of 32-k stages
+// 8 waves, each a 128x64 block of the 256x256 tile (32 accumulator tiles).  K advances in steps of 32: one
+// step = a READ segment (12 fragment reads of the step's stage, LDS-DMA issue of the stage PP_DIST steps
+// ahead) and an MFMA segment (32 x v_mfma_f32_16x16x32_bf16), separated by s_barrier.  Waves 4-7 run one
+// barrier behind waves 0-3, so on every SIMD one of its two resident waves is in an MFMA segment while the
+// other fetches operands (MI355X_MICROARCH.md "Two waves per SIMD").
+//   Stages: PP_NB buffers of 32 KiB (A 256 rows x 32 k, B 256 cols x 32 k) used as a ring; step s reads buffer
+//   s % PP_NB and issues step s + PP_DIST into the buffer step s - 1 used (PP_NB = PP_DIST + 1).  The L2 -> LDS fill
+//   is what bounds this kernel (64 KiB per 64 k per CU; a CU fills ~70 GB/s from L2 and ~30 GB/s from the
+//   Infinity Cache), so the ring keeps 3-4 stages = 96-128 KiB in flight per CU.
+//   barrier pairing: the early group's barrier n is the late group's barrier n-1.
+//   RAW: a wave drains its own pieces of step s+1 (counted vmcnt) before the barrier that closes its READ
+//        segment of step s; anyone's first read of step s+1 comes after both groups passed that barrier.
+//   WAR: the buffer of step s-1 is overwritten from READ segment s on; the late group's reads of step s-1
+//        completed (lgkmcnt(0)) before the barrier the early group passes on entering READ segment s.
+constexpr int PP_STAGE = 2 * 256 * 64;   // 32 KiB
+constexpr int pp_nb(int dist) { return dist + 1 < 4 ? 4 : dist + 1; }   // 4 buffers = 128 KiB, 5 = all 160 KiB of LDS
+
+template <typename TOut, bool A_KM, bool B_KM, int PP_DIST>
 __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
+  constexpr int PP_NB = pp_nb(PP_DIST);
   constexpr int BM = 256, BN = 256;
-  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int A_BYTES = BM * 64;
   constexpr bool SWAP = sizeof(TOut) == 2;   // bf16 output: transposed accumulators + direct_epilogue
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -595,11 +654,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
   const int bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  // Each XCD owns a contiguous run of this order: `group_n` column tiles wide, all the way down the rows, then
+  // the next group (group_n = tiles_n is plain row-major).
+  int tm, tn;
+  {
+    const int G = p.group_n, per_group = p.tiles_m * G;
+    const int gi = tile / per_group;
+    const int full = p.tiles_n / G;
+    if (gi < full) {
+      const int r = tile - gi * per_group;
+      tm = r / G;
+      tn = gi * G + (r - tm * G);
+    } else {
+      const int gsz = p.tiles_n - full * G;
+      const int r = tile - full * per_group;
+      tm = r / gsz;
+      tn = full * G + (r - tm * gsz);
+    }
+  }
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const int64_t kbeg = (int64_t)blockIdx.z * p.k_chunk;
   const int64_t kend = (kbeg + p.k_chunk < p.K) ? kbeg + p.k_chunk : p.K;
   const int nk = (int)((kend - kbeg + T_BK - 1) / T_BK);
+  const int nhs = 2 * nk;                      // 32-deep steps
 
   const int64_t lda_b = p.lda * 2, ldb_b = p.ldb * 2;
   const char* a_base;
@@ -622,78 +699,68 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto issue = [&](int kt) {
-    char* st = smem + (kt & 1) * STAGE;
-    stage_tile<A_KM, BM, 8>(rsA, lda_b, a_k0 + (int64_t)kt * T_BK, a_col0, st, wave, lane);
-    stage_tile<B_KM, BN, 8>(rsB, ldb_b, b_k0 + (int64_t)kt * T_BK, b_col0, st + A_BYTES, wave, lane);
+  // step hs (32 k) -> ring buffer `buf`: 4 LDS-DMA pieces per wave (2 of A, 2 of B)
+  auto issue_step = [&](int hs, int buf) {
+    char* st = smem + buf * PP_STAGE;
+    stage_step<A_KM, BM, 8>(rsA, lda_b, a_k0 + (int64_t)hs * 32, a_col0, st, wave, lane);
+    stage_step<B_KM, BN, 8>(rsB, ldb_b, b_k0 + (int64_t)hs * 32, b_col0, st + A_BYTES, wave, lane);
   };
-  if (nk > 0) issue(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  auto wait_pieces = [&](int halves) {           // all but the youngest `halves` steps of this wave have landed
+    if (halves >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (halves == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (halves == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  static_assert(PP_DIST >= 2 && PP_DIST <= 4, "wait_pieces assumes at most 3 steps left in flight");
+#pragma unroll
+  for (int h = 0; h < PP_DIST; ++h)
+    if (h < nhs) issue_step(h, h);            // PP_DIST <= PP_NB - 1
+  wait_pieces((nhs < PP_DIST ? nhs : PP_DIST) - 1);     // step 0 has landed
   __builtin_amdgcn_s_barrier();
   if (late) __builtin_amdgcn_s_barrier();      // the stagger: waves 4-7 run one segment behind
   __builtin_amdgcn_sched_barrier(0);
+  unsigned long long t_cyc = 0, t_real = 0;
+  if (p.stamps) { t_cyc = __builtin_amdgcn_s_memtime(); t_real = __builtin_amdgcn_s_memrealtime(); }
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* cur = smem + (kt & 1) * STAGE;
-    bf16x8 b[4];
-    if constexpr (PHASES == 4) {
+  int b_rd = 0, b_wr = PP_DIST % PP_NB;        // b_wr == (hs + PP_DIST) % PP_NB: a buffer last read at step hs - 1 or earlier
+  for (int hs = 0; hs < nhs; ++hs) {
+    const char* cur = smem + b_rd * PP_STAGE;
+    bf16x8 a[8], b[4];
 #pragma unroll
-      for (int ph = 0; ph < 4; ++ph) {
-        const int ks = ph >> 1, mh = ph & 1;
-        // ---------------- READ segment
-        bf16x8 a[4];
-        if (mh == 0) {
+    for (int j = 0; j < 4; ++j) b[j] = load_frag_h<B_KM, BN>(cur + A_BYTES, wc * 64 + j * 16, lane);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) b[j] = load_frag<B_KM, BN>(cur + A_BYTES, wc * 64 + j * 16, ks, lane);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = load_frag<A_KM, BM>(cur, wr * 128 + mh * 64 + i * 16, ks, lane);
-        if (ph == 0 && kt + 1 < nk) issue(kt + 1);
-        if (ph == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---------------- MFMA segment
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[mh * 4 + i][j] = SWAP ? mfma_bf16(b[j], a[i], acc[mh * 4 + i][j]) : mfma_bf16(a[i], b[j], acc[mh * 4 + i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      // two phases of 32 MFMAs (one per k-step): half the barriers, 48 fragment registers
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 a[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = load_frag<B_KM, BN>(cur + A_BYTES, wc * 64 + j * 16, ks, lane);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = load_frag<A_KM, BM>(cur, wr * 128 + i * 16, ks, lane);
-        if (ks == 0 && kt + 1 < nk) issue(kt + 1);
-        if (ks == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = SWAP ? mfma_bf16(b[j], a[i], acc[i][j]) : mfma_bf16(a[i], b[j], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-      }
+    for (int i = 0; i < 8; ++i) a[i] = load_frag_h<A_KM, BM>(cur, wr * 128 + i * 16, lane);
+    if (hs + PP_DIST < nhs) issue_step(hs + PP_DIST, b_wr);
+    {
+      // steps issued so far reach min(hs + PP_DIST, nhs - 1); step hs + 1 must have landed when this segment closes
+      const int last = hs + PP_DIST < nhs - 1 ? hs + PP_DIST : nhs - 1;
+      const int fly = last - (hs + 1);
+      wait_pieces(fly > 0 ? fly : 0);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = SWAP ? mfma_bf16(b[j], a[i], acc[i][j]) : mfma_bf16(a[i], b[j], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    b_wr = b_wr + 1 == PP_NB ? 0 : b_wr + 1;
+    b_rd = b_rd + 1 == PP_NB ? 0 : b_rd + 1;
   }
   if (!late) __builtin_amdgcn_s_barrier();     // equalise the barrier count of the two groups
+  if (p.stamps && tid == 0) {
+    unsigned long long* o = p.stamps + 4 * ((size_t)blockIdx.z * gridDim.x + blockIdx.x);
+    o[0] = __builtin_amdgcn_s_memtime() - t_cyc;
+    o[1] = __builtin_amdgcn_s_memrealtime() - t_real;
+    o[2] = (unsigned long long)nk;
+    o[3] = t_real;
+  }
   if constexpr (SWAP) {
     direct_epilogue(p, acc, lane, m0 + wr * 128, n0 + wc * 64);
     return;
@@ -857,13 +924,64 @@ static int launch_tile256(hipStream_t st, const GemmParams& p, int ta, int tb) {
   return check_launch("gemm_bf16_tile256");
 }
 
+// MDT_GEMM_STAMP=1: every ping-pong launch is followed by a device sync and one stderr line with the median
+// in-kernel clock and shader cycles per 64-deep K-tile of its main loop (tools/kbench.py; never in production).
+static void report_stamps(unsigned long long* dev, size_t nwg, const GemmParams& p) {
+  std::vector<unsigned long long> h(nwg * 4);
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h.data(), dev, nwg * 32, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
+  std::vector<double> cyc, clk;
+  unsigned long long t0 = ~0ull, t1 = 0;
+  for (size_t i = 0; i < nwg; ++i) {
+    if (h[4 * i + 2] == 0 || h[4 * i + 1] == 0) continue;
+    cyc.push_back((double)h[4 * i] / (double)h[4 * i + 2]);
+    clk.push_back((double)h[4 * i] / (double)h[4 * i + 1] * 100.0);
+    t0 = std::min(t0, h[4 * i + 3]);
+    t1 = std::max(t1, h[4 * i + 3] + h[4 * i + 1]);
+  }
+  if (cyc.empty()) return;
+  std::sort(cyc.begin(), cyc.end());
+  std::sort(clk.begin(), clk.end());
+  fprintf(stderr, "[mdt gemm stamp] M=%lld N=%lld K=%lld wgs=%zu  cycles/k-tile median %.0f (p10 %.0f p90 %.0f)  clock median %.0f MHz  span %.1f us\n",
+          (long long)p.M, (long long)p.N, (long long)p.K, nwg, cyc[cyc.size() / 2], cyc[cyc.size() / 10], cyc[cyc.size() * 9 / 10],
+          clk[clk.size() / 2], (double)(t1 - t0) / 100.0);
+}
+
 template <typename TOut>
-static int launch_pp256(hipStream_t st, const GemmParams& p, int ta, int tb) {
+static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) {
+  GemmParams p = p_in;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)p.split_k);
-  const size_t lds = (size_t)2 * 512 * 128;
-#define LPP(A_, B_, PH_)                                                                                        \
+  {
+    // fabric-read model per choice of G: A is re-read once per column group; a group whose B panels exceed
+    // ~1.6 MB does not survive in L2 next to the streaming A, so B is re-read by every wave of tiles on every XCD
+    const double a_bytes = (double)p.M * (double)p.k_chunk * 2.0, b_bytes = (double)p.N * (double)p.k_chunk * 2.0;
+    const double rounds = (double)p.tiles_m * p.tiles_n / 256.0;
+    int best = p.tiles_n;
+    double best_cost = 1e300;
+    for (int G = 1; G <= p.tiles_n; ++G) {
+      const int ngroups = (p.tiles_n + G - 1) / G;
+      const bool fits = (double)G * 256.0 * (double)p.k_chunk * 2.0 <= 1.6e6;
+      const double cost = a_bytes * ngroups + (fits ? b_bytes * 8.0 : b_bytes * 8.0 * (rounds > 1.0 ? rounds : 1.0));
+      if (cost < best_cost * 0.999) { best_cost = cost; best = G; }
+    }
+    // measured at the C2 shapes: the grouped order does cut fabric reads but runs 2 % slower (A then streams from
+    // HBM instead of the Infinity Cache), so row-major stays the default and the model only serves MDT_GEMM_GROUP=0
+    p.group_n = p.tiles_n;
+    if (const char* g = getenv("MDT_GEMM_GROUP")) { if (atoi(g) == 0) p.group_n = best; }
+    if (const char* g = getenv("MDT_GEMM_GROUP")) { const int v = atoi(g); if (v >= 1) p.group_n = v < p.tiles_n ? v : p.tiles_n; }
+  }
+  static const bool stamp = getenv("MDT_GEMM_STAMP") != nullptr;
+  const size_t nwg = (size_t)grid.x * grid.z;
+  if (stamp) {
+    if (hipMalloc(&p.stamps, nwg * 32) != hipSuccess) { (void)hipGetLastError(); p.stamps = nullptr; }
+    else (void)hipMemsetAsync(p.stamps, 0, nwg * 32, st);
+  }
+  // prefetch distance in 32-k steps.  In-call A/B at the C2 shapes: 4 (five stages = all of LDS) beats 2 and 3 by
+  // 1-3 % per GEMM, 0.6 % on the whole step — the fill is throughput- rather than latency-bound
+  static const int dist = getenv("MDT_GEMM_PP_DIST") ? atoi(getenv("MDT_GEMM_PP_DIST")) : 4;
+#define LPP(A_, B_, D_)                                                                                      \
   {                                                                                                          \
-    auto kern = gemm_bf16_pp256<TOut, A_, B_, PH_>;                                                          \
+    const size_t lds = (size_t)pp_nb(D_) * PP_STAGE;                                                         \
+    auto kern = gemm_bf16_pp256<TOut, A_, B_, D_>;                                                           \
     static bool attr_set = false;                                                                            \
     if (!attr_set) {                                                                                         \
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
@@ -875,19 +993,22 @@ static int launch_pp256(hipStream_t st, const GemmParams& p, int ta, int tb) {
     }                                                                                                        \
     hipLaunchKernelGGL(kern, grid, 512, lds, st, p);                                                         \
   }
-  const bool two = getenv("MDT_GEMM_PP_PHASES") == nullptr || atoi(getenv("MDT_GEMM_PP_PHASES")) == 2;   // measured: 2 phases of 32 MFMAs beat 4 x 16 by 3-10 %
-  if (two) {
-    if (!ta && !tb) LPP(false, false, 2)
-    else if (!ta && tb) LPP(false, true, 2)
-    else if (ta && !tb) LPP(true, false, 2)
-    else LPP(true, true, 2)
-  } else {
-    if (!ta && !tb) LPP(false, false, 4)
-    else if (!ta && tb) LPP(false, true, 4)
-    else if (ta && !tb) LPP(true, false, 4)
-    else LPP(true, true, 4)
+#define LPPD(D_)                          \
+  {                                       \
+    if (!ta && !tb) LPP(false, false, D_) \
+    else if (!ta && tb) LPP(false, true, D_) \
+    else if (ta && !tb) LPP(true, false, D_) \
+    else LPP(true, true, D_)              \
   }
+  if (dist >= 4) LPPD(4)
+  else if (dist == 3) LPPD(3)
+  else LPPD(2)
+#undef LPPD
 #undef LPP
+  if (p.stamps) {
+    report_stamps(p.stamps, nwg, p);
+    (void)hipFree(p.stamps);
+  }
   return check_launch("gemm_bf16_pp256");
 }
 
@@ -922,6 +1043,9 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_DROPOUT) || M * N < DROP_MAX_ELEMS, "mdt_gemm: dropout site of %lld elements (limit 2^33)", (long long)(M * N));
   p.drop = make_drop((epilogue & MDT_EPI_DROPOUT) ? drop_p : 0.f, drop_seed);
   p.colsum = colsum;
+  p.stamps = nullptr;
+  p.group_n = 1;
+  if (const char* dg = getenv("MDT_GEMM_DIAG")) p.epilogue |= atoi(dg) << 20;   // 1: skip stores, 2: sc1 stores (direct epilogue only)
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_COLSUM) || (colsum && split_k == 1), "mdt_gemm: MDT_EPI_COLSUM needs a colsum buffer and split_k == 1");
   // tile128 contract: bf16, output dims that are tiled along a contiguous axis must be
   // whole tiles, 16-B aligned rows.

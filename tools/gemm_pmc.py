@@ -1,7 +1,9 @@
-"""A handful of GEMM launches for PMC collection (rocprofv3 --pmc ...)."""
+"""A handful of GEMM launches for PMC collection (rocprofv3 --pmc ...). MDT_GEMM_DIAG variants via --diag."""
 import os
 import sys
 
+if "--diag" in sys.argv:
+    os.environ["MDT_GEMM_DIAG"] = sys.argv[sys.argv.index("--diag") + 1]
 import torch
 
 sys.path.insert(0, ".")
@@ -9,7 +11,7 @@ from multimodaldiscussiontransformer_amd import ops  # noqa: E402
 
 M = 212992
 bf = torch.bfloat16
-cases = [(M, 3072, 768, 0, 0), (M, 768, 3072, 0, 0), (M, 768, 3072, 0, 1)]
+cases = [(M, 3072, 768, 0, 0), (M, 768, 3072, 0, 0), (M, 768, 3072, 0, 1), (M, 3072, 768, 0, 1)]
 for (m, n, k, ta, tb) in cases:
     a = torch.randn(m, k, device="cuda", dtype=bf)
     b = torch.randn(k, n, device="cuda", dtype=bf) if tb else torch.randn(n, k, device="cuda", dtype=bf)
