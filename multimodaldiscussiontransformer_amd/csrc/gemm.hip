@@ -776,6 +776,148 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------ persistent form of the ping-pong kernel
+// One workgroup per CU walks tiles v = blockIdx.x, + gridDim.x, ... (the XCD-aware order above holds because
+// gridDim.x is a multiple of 8).  The stage ring simply keeps turning across tile boundaries: the last PP_DIST
+// steps of a tile issue the first PP_DIST steps of the NEXT tile, so its operands land while this tile's
+// register-resident epilogue (no LDS, no barrier) runs — the ~2 us first-fetch latency and the workgroup
+// launch / drain that a 12-step (K = 768) tile pays per tile otherwise are gone.  At a boundary the early
+// group takes one extra barrier so both groups run their epilogues at the same time, and the stagger is
+// re-created on entry to the next tile.  bf16 output, split_k == 1, at least PP_DIST steps per tile.
+template <bool A_KM, bool B_KM, int PP_DIST>
+__global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
+  constexpr int PP_NB = pp_nb(PP_DIST);
+  constexpr int BM = 256, BN = 256;
+  constexpr int A_BYTES = BM * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const bool late = wave >= 4;
+  const int nvt = p.tiles_m * p.tiles_n;
+  const int nhs = 2 * (int)((p.K + T_BK - 1) / T_BK);
+  const int64_t lda_b = p.lda * 2, ldb_b = p.ldb * 2;
+
+  struct Desc { __amdgpu_buffer_rsrc_t rsA, rsB; int a_col0, b_col0; int64_t m0, n0; };
+  auto make_desc = [&](int v) {
+    const int q8 = nvt >> 3, r8 = nvt & 7, xcd = v & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3);
+    int tm, tn;
+    {
+      const int G = p.group_n, per_group = p.tiles_m * G;
+      const int gi = tile / per_group;
+      const int full = p.tiles_n / G;
+      if (gi < full) {
+        const int r = tile - gi * per_group;
+        tm = r / G;
+        tn = gi * G + (r - tm * G);
+      } else {
+        const int gsz = p.tiles_n - full * G;
+        const int r = tile - full * per_group;
+        tm = r / gsz;
+        tn = full * G + (r - tm * gsz);
+      }
+    }
+    Desc d;
+    d.m0 = (int64_t)tm * BM;
+    d.n0 = (int64_t)tn * BN;
+    const char* a_base;
+    const char* b_base;
+    int64_t a_bytes, b_bytes;
+    if constexpr (!A_KM) { a_base = (const char*)p.A + d.m0 * lda_b; a_bytes = (p.M - d.m0) * lda_b; }
+    else { a_base = (const char*)p.A; a_bytes = p.K * lda_b; }
+    if constexpr (!B_KM) { b_base = (const char*)p.B + d.n0 * ldb_b; b_bytes = (p.N - d.n0) * ldb_b; }
+    else { b_base = (const char*)p.B; b_bytes = p.K * ldb_b; }
+    const unsigned a_rec = (unsigned)(a_bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : a_bytes);
+    const unsigned b_rec = (unsigned)(b_bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : b_bytes);
+    d.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, a_rec, 0x00020000);
+    d.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, b_rec, 0x00020000);
+    d.a_col0 = A_KM ? (int)d.m0 : 0;
+    d.b_col0 = B_KM ? (int)d.n0 : 0;
+    return d;
+  };
+  auto issue_step = [&](const Desc& d, int hs, int buf) {
+    char* st = smem + buf * PP_STAGE;
+    stage_step<A_KM, BM, 8>(d.rsA, lda_b, (int64_t)hs * 32, d.a_col0, st, wave, lane);
+    stage_step<B_KM, BN, 8>(d.rsB, ldb_b, (int64_t)hs * 32, d.b_col0, st + A_BYTES, wave, lane);
+  };
+  auto wait_pieces = [&](int halves) {
+    if (halves >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (halves == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (halves == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  static_assert(PP_DIST >= 2 && PP_DIST <= 4, "wait_pieces assumes at most 3 steps left in flight");
+
+  int v = blockIdx.x;
+  Desc cur = make_desc(v);
+  bool has_next = v + (int)gridDim.x < nvt;
+  Desc nxt = make_desc(has_next ? v + (int)gridDim.x : v);
+#pragma unroll
+  for (int h = 0; h < PP_DIST; ++h) issue_step(cur, h, h);       // host guarantees nhs >= PP_DIST
+  wait_pieces(PP_DIST - 1);
+  int b_rd = 0, b_wr = PP_DIST % PP_NB;
+  unsigned long long t_cyc = 0, t_real = 0, s_cyc = 0, s_real = 0, s_nk = 0, t_first = 0;
+
+  for (;;) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();      // the stagger: waves 4-7 run one segment behind
+    __builtin_amdgcn_sched_barrier(0);
+    if (p.stamps) { t_cyc = __builtin_amdgcn_s_memtime(); t_real = __builtin_amdgcn_s_memrealtime(); if (!t_first) t_first = t_real; }
+    for (int hs = 0; hs < nhs; ++hs) {
+      const char* rd = smem + b_rd * PP_STAGE;
+      bf16x8 a[8], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = load_frag_h<B_KM, BN>(rd + A_BYTES, wc * 64 + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = load_frag_h<A_KM, BM>(rd, wr * 128 + i * 16, lane);
+      const int tgt = hs + PP_DIST;
+      if (tgt < nhs) {
+        issue_step(cur, tgt, b_wr);
+        wait_pieces(PP_DIST - 1);
+      } else if (has_next) {
+        issue_step(nxt, tgt - nhs, b_wr);
+        wait_pieces(PP_DIST - 1);
+      } else {
+        wait_pieces(nhs - 2 - hs > 0 ? nhs - 2 - hs : 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(b[j], a[i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      b_wr = b_wr + 1 == PP_NB ? 0 : b_wr + 1;
+      b_rd = b_rd + 1 == PP_NB ? 0 : b_rd + 1;
+    }
+    if (!late) __builtin_amdgcn_s_barrier();     // both groups leave the tile together
+    if (p.stamps) { s_cyc += __builtin_amdgcn_s_memtime() - t_cyc; s_real += __builtin_amdgcn_s_memrealtime() - t_real; s_nk += nhs / 2; }
+    direct_epilogue(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 64);
+    if (!has_next) break;
+    v += gridDim.x;
+    cur = nxt;
+    has_next = v + (int)gridDim.x < nvt;
+    if (has_next) nxt = make_desc(v + (int)gridDim.x);
+  }
+  if (p.stamps && tid == 0) {
+    unsigned long long* o = p.stamps + 4 * (size_t)blockIdx.x;
+    o[0] = s_cyc; o[1] = s_real; o[2] = s_nk; o[3] = t_first;
+  }
+}
+
 // ------------------------------------------------------------------ helpers
 template <typename TIn, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void colsum_kernel(int64_t M, int64_t N, const TIn* X, int64_t ldx, float* out,
@@ -946,28 +1088,50 @@ static void report_stamps(unsigned long long* dev, size_t nwg, const GemmParams&
           clk[clk.size() / 2], (double)(t1 - t0) / 100.0);
 }
 
+static int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+    n &= ~7;                      // the XCD-aware tile order needs a grid that is a multiple of the 8 XCDs
+    if (n < 8) n = 8;
+  }
+  return n;
+}
+
 template <typename TOut>
 static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) {
   GemmParams p = p_in;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)p.split_k);
+  static const int dist = getenv("MDT_GEMM_PP_DIST") ? atoi(getenv("MDT_GEMM_PP_DIST")) : 4;
+  static const bool persist_ok = getenv("MDT_GEMM_PERSIST") == nullptr || atoi(getenv("MDT_GEMM_PERSIST")) != 0;
+  const int nhs_total = 2 * (int)((p.K + T_BK - 1) / T_BK);
+  const bool persist = persist_ok && sizeof(TOut) == 2 && p.split_k == 1 && nhs_total >= 4 && (int)grid.x > num_cus();
+  if (persist) grid.x = (unsigned)num_cus();
   {
-    // fabric-read model per choice of G: A is re-read once per column group; a group whose B panels exceed
-    // ~1.6 MB does not survive in L2 next to the streaming A, so B is re-read by every wave of tiles on every XCD
-    const double a_bytes = (double)p.M * (double)p.k_chunk * 2.0, b_bytes = (double)p.N * (double)p.k_chunk * 2.0;
-    const double rounds = (double)p.tiles_m * p.tiles_n / 256.0;
-    int best = p.tiles_n;
-    double best_cost = 1e300;
-    for (int G = 1; G <= p.tiles_n; ++G) {
-      const int ngroups = (p.tiles_n + G - 1) / G;
-      const bool fits = (double)G * 256.0 * (double)p.k_chunk * 2.0 <= 1.6e6;
-      const double cost = a_bytes * ngroups + (fits ? b_bytes * 8.0 : b_bytes * 8.0 * (rounds > 1.0 ? rounds : 1.0));
-      if (cost < best_cost * 0.999) { best_cost = cost; best = G; }
-    }
-    // measured at the C2 shapes: the grouped order does cut fabric reads but runs 2 % slower (A then streams from
-    // HBM instead of the Infinity Cache), so row-major stays the default and the model only serves MDT_GEMM_GROUP=0
+    // Tile order: row-major by default (group_n = tiles_n).  MDT_GEMM_GROUP=0 picks the width from a fabric-read
+    // model (A re-read once per column group; a group whose B panels exceed ~1.6 MB is re-read from the Infinity
+    // Cache by every wave of tiles), MDT_GEMM_GROUP=n forces n.  Measured in one call at the C2 shapes: the model's
+    // choice does cut fabric reads (2.7 -> ~1.5 GB for N = 3072, K = 768) but runs 2-5 % slower — A then streams
+    // from HBM three times instead of once — so it is not the default.
     p.group_n = p.tiles_n;
-    if (const char* g = getenv("MDT_GEMM_GROUP")) { if (atoi(g) == 0) p.group_n = best; }
-    if (const char* g = getenv("MDT_GEMM_GROUP")) { const int v = atoi(g); if (v >= 1) p.group_n = v < p.tiles_n ? v : p.tiles_n; }
+    if (const char* g = getenv("MDT_GEMM_GROUP")) {
+      int v = atoi(g);
+      if (v == 0) {
+        const double a_bytes = (double)p.M * (double)p.k_chunk * 2.0, b_bytes = (double)p.N * (double)p.k_chunk * 2.0;
+        const double rounds = (double)p.tiles_m * p.tiles_n / 256.0;
+        double best_cost = 1e300;
+        for (int G = 1; G <= p.tiles_n; ++G) {
+          const int ngroups = (p.tiles_n + G - 1) / G;
+          const bool fits = (double)G * 256.0 * (double)p.k_chunk * 2.0 <= 1.6e6;
+          const double cost = a_bytes * ngroups + (fits ? b_bytes * 8.0 : b_bytes * 8.0 * (rounds > 1.0 ? rounds : 1.0));
+          if (cost < best_cost * 0.999) { best_cost = cost; v = G; }
+        }
+      }
+      if (v >= 1) p.group_n = v < p.tiles_n ? v : p.tiles_n;
+    }
   }
   static const bool stamp = getenv("MDT_GEMM_STAMP") != nullptr;
   const size_t nwg = (size_t)grid.x * grid.z;
@@ -977,7 +1141,33 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   }
   // prefetch distance in 32-k steps.  In-call A/B at the C2 shapes: 4 (five stages = all of LDS) beats 2 and 3 by
   // 1-3 % per GEMM, 0.6 % on the whole step — the fill is throughput- rather than latency-bound
-  static const int dist = getenv("MDT_GEMM_PP_DIST") ? atoi(getenv("MDT_GEMM_PP_DIST")) : 4;
+  if (persist) {
+    const size_t lds = (size_t)pp_nb(4) * PP_STAGE;
+#define LPS(A_, B_)                                                                                          \
+  {                                                                                                          \
+    auto kern = gemm_bf16_pp256p<A_, B_, 4>;                                                                 \
+    static bool attr_set = false;                                                                            \
+    if (!attr_set) {                                                                                         \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+        (void)hipGetLastError();                                                                             \
+        set_error("gemm_bf16_pp256p: cannot reserve %zu bytes of LDS", lds);                                 \
+        return MDT_ERR_LAUNCH;                                                                               \
+      }                                                                                                      \
+      attr_set = true;                                                                                       \
+    }                                                                                                        \
+    hipLaunchKernelGGL(kern, grid, 512, lds, st, p);                                                         \
+  }
+    if (!ta && !tb) LPS(false, false)
+    else if (!ta && tb) LPS(false, true)
+    else if (ta && !tb) LPS(true, false)
+    else LPS(true, true)
+#undef LPS
+    if (p.stamps) {
+      report_stamps(p.stamps, nwg, p);
+      (void)hipFree(p.stamps);
+    }
+    return check_launch("gemm_bf16_pp256p");
+  }
 #define LPP(A_, B_, D_)                                                                                      \
   {                                                                                                          \
     const size_t lds = (size_t)pp_nb(D_) * PP_STAGE;                                                         \
@@ -1044,7 +1234,7 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   p.drop = make_drop((epilogue & MDT_EPI_DROPOUT) ? drop_p : 0.f, drop_seed);
   p.colsum = colsum;
   p.stamps = nullptr;
-  p.group_n = 1;
+  p.group_n = 1 << 30;   // row-major unless launch_pp256 decides otherwise
   if (const char* dg = getenv("MDT_GEMM_DIAG")) p.epilogue |= atoi(dg) << 20;   // 1: skip stores, 2: sc1 stores (direct epilogue only)
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_COLSUM) || (colsum && split_k == 1), "mdt_gemm: MDT_EPI_COLSUM needs a colsum buffer and split_k == 1");
   // tile128 contract: bf16, output dims that are tiled along a contiguous axis must be
