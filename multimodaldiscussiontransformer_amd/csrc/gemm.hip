@@ -1111,12 +1111,19 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   const bool persist = persist_ok && sizeof(TOut) == 2 && p.split_k == 1 && nhs_total >= 4 && (int)grid.x > num_cus();
   if (persist) grid.x = (unsigned)num_cus();
   {
-    // Tile order: row-major by default (group_n = tiles_n).  MDT_GEMM_GROUP=0 picks the width from a fabric-read
-    // model (A re-read once per column group; a group whose B panels exceed ~1.6 MB is re-read from the Infinity
-    // Cache by every wave of tiles), MDT_GEMM_GROUP=n forces n.  Measured in one call at the C2 shapes: the model's
-    // choice does cut fabric reads (2.7 -> ~1.5 GB for N = 3072, K = 768) but runs 2-5 % slower — A then streams
-    // from HBM three times instead of once — so it is not the default.
+    // Tile order.  Row-major (group_n = tiles_n) unless B is too wide for an XCD's 4-MiB L2 and splits evenly in
+    // two halves that do fit: then XCDs 0-3 sweep the left half of the columns and XCDs 4-7 the right half, over the
+    // same rows at the same time — each XCD keeps its half of B resident and the second reader of an A panel finds
+    // it in the Infinity Cache.  In-call A/B at N = 3072, K = 768: +3-4 % (fabric reads 2.7 -> ~1.3 GB).  Finer
+    // groups lose (A then streams from HBM once per group); odd splits (N = 2304) lose.  MDT_GEMM_GROUP=n forces a
+    // width, MDT_GEMM_GROUP=0 asks the fabric-read model below.
     p.group_n = p.tiles_n;
+    {
+      const double b_panel = 256.0 * (double)p.k_chunk * 2.0;
+      if (p.split_k == 1 && p.tiles_n % 2 == 0 && b_panel * p.tiles_n > 3.5e6 && b_panel * (p.tiles_n / 2) <= 2.5e6 &&
+          (double)p.tiles_m * p.tiles_n >= 4.0 * num_cus())
+        p.group_n = p.tiles_n / 2;
+    }
     if (const char* g = getenv("MDT_GEMM_GROUP")) {
       int v = atoi(g);
       if (v == 0) {
