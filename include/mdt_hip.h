@@ -45,6 +45,10 @@ enum {
   MDT_EPI_ATOMIC = 32,   /* C (fp32) += result with float atomics (split-K weight gradients) */
   MDT_EPI_COLSUM = 128,  /* colsum[n] += sum_m C[m, n] (fp32 atomics) — the bias gradient of the layer whose
                             output gradient this GEMM produces, fused instead of a separate pass */
+  MDT_EPI_AUX_GRAD = 256, /* with MDT_EPI_GELU and aux != NULL: aux receives d out / d pre-activation
+                            (GELU'(u), times the dropout scale of the element when MDT_EPI_DROPOUT is set)
+                            instead of u — the backward pass is then a plain MDT_EPI_MULAUX */
+  MDT_EPI_MULAUX = 512,  /* * aux[m, n] (backward of an epilogue that saved its derivative) */
   MDT_EPI_DROPOUT = 64   /* inverted dropout on the value after bias / GELU and before the residual add
                             (with MDT_EPI_DGELU: on the incoming gradient, before the GELU' factor);
                             element (m, n) of site `drop_seed` uses counter m*N + n */

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -43,13 +44,20 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t row,
   if (row >= p.M || col >= p.N) return;
   v *= p.alpha;
   if (p.epilogue & MDT_EPI_BIAS) v += to_f32(((const TIn*)p.bias)[col]);
-  if (p.epilogue & MDT_EPI_GELU) {
-    if (p.aux) ((TIn*)p.aux)[row * p.ldaux + col] = from_f32<TIn>(v);
-    // the saved pre-activation is what backward differentiates at: use the rounded value
-    if (p.aux) v = to_f32(from_f32<TIn>(v));
-    v = gelu_erf(v);
+  if ((p.epilogue & MDT_EPI_GELU) && (p.epilogue & MDT_EPI_AUX_GRAD)) {
+    const float m = (p.epilogue & MDT_EPI_DROPOUT) ? drop_scale(p.drop, (uint64_t)row * p.N + col) : 1.0f;
+    if (p.aux) ((TIn*)p.aux)[row * p.ldaux + col] = from_f32<TIn>(gelu_erf_grad(v) * m);
+    v = gelu_erf(v) * m;
+  } else {
+    if (p.epilogue & MDT_EPI_GELU) {
+      if (p.aux) ((TIn*)p.aux)[row * p.ldaux + col] = from_f32<TIn>(v);
+      // the saved pre-activation is what backward differentiates at: use the rounded value
+      if (p.aux) v = to_f32(from_f32<TIn>(v));
+      v = gelu_erf(v);
+    }
+    if (p.epilogue & MDT_EPI_DROPOUT) v *= drop_scale(p.drop, (uint64_t)row * p.N + col);
   }
-  if (p.epilogue & MDT_EPI_DROPOUT) v *= drop_scale(p.drop, (uint64_t)row * p.N + col);
+  if (p.epilogue & MDT_EPI_MULAUX) v *= to_f32(((const TIn*)p.aux)[row * p.ldaux + col]);
   if (p.epilogue & MDT_EPI_DGELU) v *= gelu_erf_grad(to_f32(((const TIn*)p.aux)[row * p.ldaux + col]));
   if (p.epilogue & MDT_EPI_RESIDUAL) v += to_f32(((const TIn*)p.residual)[row * p.ldr + col]);
   if (p.epilogue & MDT_EPI_COLSUM) atomicAdd(p.colsum + col, v);
@@ -274,6 +282,24 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
+    if ((ep & MDT_EPI_GELU) && (ep & MDT_EPI_AUX_GRAD)) {
+      float sc8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sc8[e] = 1.0f;
+      if (ep & MDT_EPI_DROPOUT) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) drop_scale2(p.drop, (uint64_t)gr * p.N + gc + e, sc8[e], sc8[e + 1]);
+      }
+      bf16x8 dg;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float cdf, pdf;
+        gelu_fast_parts(v[e], cdf, pdf);
+        dg[e] = (bf16_t)(__builtin_fmaf(v[e], pdf, cdf) * sc8[e]);
+        v[e] = v[e] * cdf * sc8[e];
+      }
+      if (p.aux) *(bf16x8*)((bf16_t*)p.aux + gr * p.ldaux + gc) = dg;
+    } else {
     if (ep & MDT_EPI_GELU) {
       if (p.aux) {
         bf16x8 u;
@@ -292,6 +318,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
         v[e] *= s0;
         v[e + 1] *= s1;
       }
+    }
+    }
+    if (ep & MDT_EPI_MULAUX) {
+      const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + gr * p.ldaux + gc);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= (float)u[e];
     }
     if (ep & MDT_EPI_DGELU) {
       const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + gr * p.ldaux + gc);
@@ -369,8 +401,10 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
   for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[jp][e] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  // The eight row groups are expanded by hand (generic lambda over a compile-time index): hipcc does not unroll a
+  // loop around the convergent swap, and a rolled loop indexes the accumulators dynamically = 512 B of scratch per lane.
+  auto row_group = [&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
     const int64_t gr = m0w + 16 * i + c;
     const bool live = gr < p.M;
 #pragma unroll
@@ -378,15 +412,38 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
       float v[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, acc[i][2 * jp][r]),
-                                                         __builtin_bit_cast(unsigned, acc[i][2 * jp + 1][r]), false, false);
-        v[r] = __builtin_bit_cast(float, (unsigned)sw[0]);
-        v[4 + r] = __builtin_bit_cast(float, (unsigned)sw[1]);
+        // inline asm on purpose: with __builtin_amdgcn_permlane16_swap hipcc (ROCm 7.2) folds the four swaps of a
+        // tile pair into one and broadcasts its result (every 4-column group came out as copies of its first column).
+        // s_nop 1 = the two wait states a VALU write of either operand needs before the swap reads it (the compiler
+        // may copy the accumulator into the asm operand right before; it cannot see into the string).
+        float lo = acc[i][2 * jp][r], hi = acc[i][2 * jp + 1][r];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+        v[r] = lo;
+        v[4 + r] = hi;
       }
       if (!live) continue;
       const int64_t gc = gcs[jp];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[jp][e];
+      if ((ep & MDT_EPI_GELU) && (ep & MDT_EPI_AUX_GRAD)) {
+        // value and derivative from the same exponential; the dropout scale goes into both, so backward is one multiply
+        float sc8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sc8[e] = 1.0f;
+        if (ep & MDT_EPI_DROPOUT) {
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) drop_scale2(p.drop, (uint64_t)gr * p.N + gc + e, sc8[e], sc8[e + 1]);
+        }
+        bf16x8 dg;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float cdf, pdf;
+          gelu_fast_parts(v[e], cdf, pdf);
+          dg[e] = (bf16_t)(__builtin_fmaf(v[e], pdf, cdf) * sc8[e]);
+          v[e] = v[e] * cdf * sc8[e];
+        }
+        if (p.aux) *(bf16x8*)((bf16_t*)p.aux + gr * p.ldaux + gc) = dg;
+      } else {
       if (ep & MDT_EPI_GELU) {
         if (p.aux) {
           bf16x8 u;
@@ -405,6 +462,12 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
           v[e] *= s0;
           v[e + 1] *= s1;
         }
+      }
+      }
+      if (ep & MDT_EPI_MULAUX) {
+        const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + gr * p.ldaux + gc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= (float)u[e];
       }
       if (ep & MDT_EPI_DGELU) {
         const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + gr * p.ldaux + gc);
@@ -437,7 +500,11 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
         *(bf16x8*)cptr = o;
       }
     }
-  }
+  };
+  row_group(std::integral_constant<int, 0>{}); row_group(std::integral_constant<int, 1>{});
+  row_group(std::integral_constant<int, 2>{}); row_group(std::integral_constant<int, 3>{});
+  row_group(std::integral_constant<int, 4>{}); row_group(std::integral_constant<int, 5>{});
+  row_group(std::integral_constant<int, 6>{}); row_group(std::integral_constant<int, 7>{});
   if (ep & MDT_EPI_COLSUM) {   // the 16 lanes of a row group hold 16 rows of the same columns
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp)
@@ -1106,7 +1173,8 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   GemmParams p = p_in;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)p.split_k);
   static const int dist = getenv("MDT_GEMM_PP_DIST") ? atoi(getenv("MDT_GEMM_PP_DIST")) : 4;
-  static const bool persist_ok = getenv("MDT_GEMM_PERSIST") == nullptr || atoi(getenv("MDT_GEMM_PERSIST")) != 0;
+  const char* pe = getenv("MDT_GEMM_PERSIST");     // read per call: tests toggle it
+  const bool persist_ok = pe == nullptr || atoi(pe) != 0;
   const int nhs_total = 2 * (int)((p.K + T_BK - 1) / T_BK);
   const bool persist = persist_ok && sizeof(TOut) == 2 && p.split_k == 1 && nhs_total >= 4 && (int)grid.x > num_cus();
   if (persist) grid.x = (unsigned)num_cus();
@@ -1224,13 +1292,14 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   MDT_CHECK_ARG(A && B && C, "mdt_gemm: null operand");
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_BIAS) || bias, "mdt_gemm: MDT_EPI_BIAS without bias");
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_RESIDUAL) || residual, "mdt_gemm: MDT_EPI_RESIDUAL without residual");
-  MDT_CHECK_ARG(!(epilogue & MDT_EPI_DGELU) || aux, "mdt_gemm: MDT_EPI_DGELU without aux");
+  MDT_CHECK_ARG(!(epilogue & (MDT_EPI_DGELU | MDT_EPI_MULAUX)) || aux, "mdt_gemm: MDT_EPI_DGELU / MDT_EPI_MULAUX without aux");
+  MDT_CHECK_ARG(!(epilogue & MDT_EPI_AUX_GRAD) || (epilogue & MDT_EPI_GELU), "mdt_gemm: MDT_EPI_AUX_GRAD needs MDT_EPI_GELU");
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_ATOMIC) || out_dtype == MDT_F32, "mdt_gemm: MDT_EPI_ATOMIC needs fp32 C");
   MDT_CHECK_ARG(dtype == MDT_BF16 || out_dtype == MDT_F32, "mdt_gemm: fp32 inputs need fp32 output");
   if (split_k < 1) split_k = 1;
   MDT_CHECK_ARG(split_k == 1 || (epilogue & MDT_EPI_ATOMIC), "mdt_gemm: split_k > 1 needs MDT_EPI_ATOMIC");
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_DROPOUT) || (drop_p >= 0.f && drop_p < 1.f), "mdt_gemm: dropout p=%f out of [0,1)", drop_p);
-  MDT_CHECK_ARG(split_k == 1 || !(epilogue & (MDT_EPI_BIAS | MDT_EPI_GELU | MDT_EPI_RESIDUAL | MDT_EPI_DGELU | MDT_EPI_DROPOUT)),
+  MDT_CHECK_ARG(split_k == 1 || !(epilogue & (MDT_EPI_BIAS | MDT_EPI_GELU | MDT_EPI_RESIDUAL | MDT_EPI_DGELU | MDT_EPI_DROPOUT | MDT_EPI_MULAUX)),
                 "mdt_gemm: split_k > 1 supports only the plain accumulate epilogue");
   hipStream_t st = (hipStream_t)stream;
   GemmParams p;

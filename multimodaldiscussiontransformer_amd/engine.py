@@ -182,7 +182,9 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
     forward; the adjoint below mirrors it with the residual adds folded into epilogues.
     Dropout (training): ``p_attn`` on attention probabilities (inside the attention kernel),
     ``p_hidden`` on the two dense outputs before their residual adds and ``p_act`` after GELU
-    (both in the GEMM epilogue); masks are regenerated in backward from per-site seeds."""
+    (both in the GEMM epilogue); masks are regenerated in backward from per-site seeds.  The FFN
+    saves ``u`` = d h / d pre-activation (GELU' times the activation-dropout scale) rather than
+    the pre-activation itself, so the backward epilogue is a single multiply."""
     xd = x.data
     kw = spec.kwargs()
     s_attn, s_o, s_act, s_f2 = (tape.next_seed() for _ in range(4))
@@ -193,7 +195,7 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         t = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xd, drop_p=p_hidden, drop_seed=s_o)
         a, m1, r1 = ops.layernorm_fwd(t, P.ln1_w.data, P.ln1_b.data, eps)
         u = torch.empty(a.shape[0], P.fc1_w.shape[0], dtype=a.dtype, device=a.device)
-        h = ops.gemm(a, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU, drop_p=p_act, drop_seed=s_act)
+        h = ops.gemm(a, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act)
         y = ops.gemm(h, P.fc2_w.data, bias=P.fc2_b.data, residual=a, drop_p=p_hidden, drop_seed=s_f2)
         out, m2, r2 = ops.layernorm_fwd(y, P.ln2_w.data, P.ln2_b.data, eps)
     else:
@@ -203,7 +205,7 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         hmid = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xd, drop_p=p_hidden, drop_seed=s_o)
         n2, m2, r2 = ops.layernorm_fwd(hmid, P.ln2_w.data, P.ln2_b.data, eps)
         u = torch.empty(n2.shape[0], P.fc1_w.shape[0], dtype=n2.dtype, device=n2.device)
-        f = ops.gemm(n2, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU, drop_p=p_act, drop_seed=s_act)
+        f = ops.gemm(n2, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act)
         out = ops.gemm(f, P.fc2_w.data, bias=P.fc2_b.data, residual=hmid, drop_p=p_hidden, drop_seed=s_f2)
     o = Var(out)
 
@@ -231,7 +233,7 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         dy, dyd = _ln_bwd_dense(tape, g, y, P.ln2_w, P.ln2_b, m2, r2, P.fc2_b, p_hidden, s_f2)
         wgrad(tape, dyd, h, P.fc2_w, None)
         gb1 = tape.pgrad(P.fc1_b)           # fc1 bias gradient = colsum(du): fused into the GEMM epilogue
-        du = ops.gemm(dyd, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_DGELU, drop_p=p_act, drop_seed=s_act,
+        du = ops.gemm(dyd, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_MULAUX,
                       colsum=None if gb1 is None else gb1.view(-1))
         wgrad(tape, du, a, P.fc1_w, None)
         da = ops.gemm(du, P.fc1_w.data, trans_b=True, residual=dy)
@@ -253,7 +255,7 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         gd = hdrop(g, s_f2)
         wgrad(tape, gd, f, P.fc2_w, P.fc2_b)
         gb1 = tape.pgrad(P.fc1_b)
-        du = ops.gemm(gd, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_DGELU, drop_p=p_act, drop_seed=s_act,
+        du = ops.gemm(gd, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_MULAUX,
                       colsum=None if gb1 is None else gb1.view(-1))
         wgrad(tape, du, n2, P.fc1_w, None)
         dn2 = ops.gemm(du, P.fc1_w.data, trans_b=True)

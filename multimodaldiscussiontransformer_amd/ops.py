@@ -11,14 +11,14 @@ from typing import Optional
 import torch
 
 from . import _lib as L
-from ._lib import (EPI_ACCUM, EPI_ATOMIC, EPI_BIAS, EPI_COLSUM, EPI_DGELU, EPI_DROPOUT, EPI_GELU, EPI_RESIDUAL, check, dt, lib,
+from ._lib import (EPI_ACCUM, EPI_ATOMIC, EPI_AUX_GRAD, EPI_BIAS, EPI_COLSUM, EPI_DGELU, EPI_DROPOUT, EPI_GELU, EPI_MULAUX, EPI_RESIDUAL, check, dt, lib,
                    ptr, stream)
 
 __all__ = [
     "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "graph_attn_bias",
     "row_axpby", "row_scatter_add", "bert_embed_sum", "vit_patchify", "vit_assemble", "graph_node_feature",
     "tanh_fwd", "tanh_bwd", "node_ce", "cast", "transpose2d", "dropout", "dropout_mask",
-    "EPI_BIAS", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_ACCUM", "EPI_ATOMIC", "EPI_DROPOUT",
+    "EPI_BIAS", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_ACCUM", "EPI_ATOMIC", "EPI_DROPOUT", "EPI_AUX_GRAD", "EPI_MULAUX",
 ]
 
 

@@ -82,6 +82,33 @@ def test_gemm_epilogue_dropout(ops, dtype):
     torch.testing.assert_close(out.cpu(), x.grad, atol=2e-3, rtol=2e-3)
 
 
+@pytest.mark.parametrize("dtype,shape", [(torch.float32, (50, 40, 36)), (torch.bfloat16, (33000, 256, 128)),
+                                         (torch.bfloat16, (16640 + 37, 1024, 256))])
+def test_gemm_saved_derivative_epilogue(ops, dtype, shape):
+    """MDT_EPI_GELU | MDT_EPI_AUX_GRAD saves d out / d u = GELU'(u) * dropout scale; backward is MDT_EPI_MULAUX.
+    The third shape has more 256x256 tiles than CUs: the persistent ping-pong kernel with a ragged last row tile."""
+    M, N, K = shape
+    p, seed = 0.3, 4711
+    a, b = rnd(M, K, seed=1).to(dtype), rnd(N, K, seed=2, scale=0.3).to(dtype)
+    bias = rnd(N, seed=3).to(dtype)
+    m = mask(ops, (M, N), p, seed)
+    u = (a.float() @ b.float().t() + bias.float()).requires_grad_(True)
+    h = F.gelu(u) * m
+    h.backward(torch.ones_like(h))
+    tol = dict(atol=2e-4, rtol=1e-4) if dtype == torch.float32 else dict(atol=0.04, rtol=2e-2)
+    aux = torch.empty(M, N, dtype=dtype).cuda()
+    out = ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), aux=aux, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p, drop_seed=seed)
+    torch.testing.assert_close(out.float().cpu(), h.detach(), **tol)
+    torch.testing.assert_close(aux.float().cpu(), u.grad, **tol)
+    # backward GEMM: (g @ W) * aux, with the bias gradient (column sums) fused
+    g = rnd(M, K, seed=5).to(dtype)
+    cs = torch.zeros(N, dtype=torch.float32).cuda()
+    du = ops.gemm(g.cuda(), b.t().contiguous().cuda(), trans_b=True, aux=aux, epilogue=ops.EPI_MULAUX, colsum=cs)
+    ref = (g.float() @ b.float().t()) * aux.float().cpu()
+    torch.testing.assert_close(du.float().cpu(), ref, **tol)
+    torch.testing.assert_close(cs.cpu(), ref.sum(0), atol=0.5 if dtype == torch.bfloat16 else 1e-3, rtol=2e-2)
+
+
 @pytest.mark.parametrize("dtype,bwd", [(torch.float32, None), (torch.bfloat16, None), (torch.bfloat16, "v1"), (torch.bfloat16, "v3")])
 @pytest.mark.parametrize("nseq,S,H", [(3, 20, 2), (2, 104, 3), (2, 201, 2)])
 def test_attention_dropout(ops, dtype, bwd, nseq, S, H, monkeypatch):

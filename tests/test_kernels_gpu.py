@@ -149,6 +149,29 @@ def test_gemm_bf16_tile256_pipeline(ops, ta, tb):
         torch.testing.assert_close(c.cpu(), ref, atol=5e-3, rtol=2e-3)
 
 
+@pytest.mark.parametrize("tb", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(16640, 1024, 256), (16677, 1024, 768), (70000, 768, 128), (66000, 3072, 192)])
+def test_gemm_bf16_out_big_tiles(ops, M, N, K, tb, monkeypatch):
+    """bf16 OUTPUT through the 256x256 ping-pong kernels: register-resident epilogue (transposed accumulators +
+    lane swaps), persistent tile loop (more tiles than CUs) and its one-tile-per-workgroup form, ragged last row
+    tile, bias / residual / column sums.  (The fp32-output tests above take the LDS-parked epilogue instead.)"""
+    a = rnd(M, K, seed=1).bfloat16()
+    b = (rnd(K, N, seed=2, scale=0.3) if tb else rnd(N, K, seed=2, scale=0.3)).bfloat16()
+    bias, res = rnd(N, seed=3).bfloat16(), rnd(M, N, seed=4).bfloat16()
+    ad, bd = dev(a), dev(b)
+    ref = ad.float() @ (bd.float() if tb else bd.float().t())
+    tol = dict(atol=0.06, rtol=1.5e-2)
+    for persist in ("1", "0"):
+        monkeypatch.setenv("MDT_GEMM_PERSIST", persist)
+        out = ops.gemm(ad, bd, trans_b=bool(tb))
+        torch.testing.assert_close(out.float(), ref, **tol)
+    cs = torch.zeros(N, dtype=torch.float32).cuda()
+    out = ops.gemm(ad, bd, trans_b=bool(tb), bias=dev(bias), residual=dev(res), colsum=cs)
+    full = ref + dev(bias).float() + dev(res).float()
+    torch.testing.assert_close(out.float(), full, **tol)
+    torch.testing.assert_close(cs, full.sum(0), atol=1.0, rtol=2e-2)
+
+
 def test_colsum_cast_transpose(ops):
     x = rnd(1037, 200, seed=9)
     torch.testing.assert_close(ops.colsum(dev(x)).cpu(), x.sum(0), atol=1e-3, rtol=1e-5)
