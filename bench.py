@@ -128,12 +128,20 @@ def cpu_baseline(args):
     batch = R.to_torch_batch(S.collate(trees, 5))
     g = torch.Generator().manual_seed(0)
     W = {n: (torch.randn(s, generator=g) * 0.02).requires_grad_(True) for n, s in R.param_shapes(hp).items()}
-    t0 = time.time()
-    logits, _ = R.model_forward(W, hp, batch)
-    loss, _ = R.node_cross_entropy(logits, batch["y"], batch["y_mask"], hp)
-    loss.backward()
+    def one_pass():
+        for w in W.values():
+            w.grad = None
+        logits, _ = R.model_forward(W, hp, batch)
+        loss, _ = R.node_cross_entropy(logits, batch["y"], batch["y_mask"], hp)
+        loss.backward()
+
+    one_pass()                                   # untimed: thread pool, allocator and oneDNN primitives warm
+    passes, t0 = 0, time.time()
+    while passes < 12 and (passes == 0 or time.time() - t0 < 12.0):   # ~12 s of CPU work, at most 12 passes
+        one_pass()
+        passes += 1
     dt = time.time() - t0
-    m = n_trees * n_nodes
+    m = n_trees * n_nodes * passes
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -144,7 +152,59 @@ def cpu_baseline(args):
         pass
     return dict(value=m / dt, unit="comments/s", cores=ncores, kind="port",
                 sample=f"oracle (torch CPU fp32 restatement) fwd+bwd, {n_trees} trees x {n_nodes} comments, "
-                       f"25% image comments, mDT-base, 1 pass, {dt:.1f} s on {model}")
+                       f"25% image comments, mDT-base, {passes} timed passes after 1 warm-up, {dt:.1f} s on {model}")
+
+
+def selfcheck():
+    """Numerics guard, outside the timed region: the kernels the step spends its time in, at the bench's own shapes
+    (big-tile persistent GEMM with fused epilogues, split-K weight gradient, attention forward / backward with
+    dropout), against plain torch fp32 on the same inputs and the same dropout masks.  Raises on mismatch."""
+    import math
+
+    import torch.nn.functional as F
+    from multimodaldiscussiontransformer_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(7)
+    bf = torch.bfloat16
+    rn = lambda *sh, sc=1.0: (torch.randn(*sh, device="cuda", generator=g) * sc).to(bf)
+    tol = dict(atol=0.08, rtol=2e-2)
+    M, N, K = 65536 + 17, 3072, 768
+    a, w, bias = rn(M, K), rn(N, K, sc=0.05), rn(N)
+    u = a.float() @ w.float().t() + bias.float()
+    m = ops.dropout_mask(M * N, 0.3, 99).view(M, N).float() / 0.7
+    aux = torch.empty(M, N, device="cuda", dtype=bf)
+    h = ops.gemm(a, w, bias=bias, aux=aux, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=0.3, drop_seed=99)
+    torch.testing.assert_close(h.float(), F.gelu(u) * m, **tol)
+    ur = u.clone().requires_grad_(True)
+    (F.gelu(ur) * m).sum().backward()
+    torch.testing.assert_close(aux.float(), ur.grad, **tol)
+    del ur, m, aux, h
+    dy = rn(M, N, sc=0.1)
+    dx = ops.gemm(dy, w, trans_b=True)                              # dgrad: [M, N] x [N, K]
+    torch.testing.assert_close(dx.float(), dy.float() @ w.float(), **tol)
+    gw = torch.zeros(N, K, device="cuda", dtype=torch.float32)
+    ops.gemm(dy, a, trans_a=True, trans_b=True, out=gw, epilogue=ops.EPI_ATOMIC, split_k=7)
+    torch.testing.assert_close(gw, dy.float().t() @ a.float(), atol=0.5, rtol=2e-2)
+    del dy, dx, gw, u, a, w
+    for (nseq, S) in ((96, 104), (24, 201)):
+        H, hd, p, seed = 12, 64, 0.3, 4242
+        D = H * hd
+        qkv, dout = rn(nseq * S, 3 * D), rn(nseq * S, D)
+        km = torch.ones(nseq, S, dtype=torch.uint8, device="cuda")
+        km[1, S - 5:] = 0
+        S2 = S + (S & 1)
+        mk = (ops.dropout_mask(nseq * H * S * S2, p, seed).view(nseq, H, S, S2)[..., :S].float() / (1 - p))
+        qr = qkv.float().view(nseq, S, 3 * D).requires_grad_(True)
+        q, k, v = qr.split(D, dim=-1)
+        hv = lambda t: t.reshape(nseq, S, H, hd).transpose(1, 2)
+        sc = hv(q) @ hv(k).transpose(-1, -2) * hd ** -0.5
+        sc = sc.masked_fill(~km.bool()[:, None, None, :], -math.inf)
+        oref = ((torch.softmax(sc, -1) * mk) @ hv(v)).transpose(1, 2).reshape(nseq * S, D)
+        oref.backward(dout.float())
+        out, lse = ops.attention_fwd(qkv, nseq, S, H, key_mask=km, drop_p=p, drop_seed=seed)
+        torch.testing.assert_close(out.float(), oref.detach(), atol=0.05, rtol=3e-2)
+        dqkv, _ = ops.attention_bwd(dout, qkv, out, lse, nseq, S, H, key_mask=km, drop_p=p, drop_seed=seed)
+        torch.testing.assert_close(dqkv.float().view(nseq, S, 3 * D), qr.grad, atol=0.1, rtol=6e-2)
+    torch.cuda.synchronize()
 
 
 def main():
@@ -163,6 +223,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
+    ap.add_argument("--no-selfcheck", action="store_true", help="skip the numerics guard that runs before the warm-up")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -183,6 +244,8 @@ def main():
     from multimodaldiscussiontransformer_amd.ddp import DataParallel
     from multimodaldiscussiontransformer_amd.models import GraphormerModel
 
+    if args.dtype == "bf16" and not args.no_selfcheck:
+        selfcheck()
     timer = GemmTimer()
     if not args.no_gemm_timer:
         timer.install()
@@ -262,6 +325,7 @@ def main():
             "model_tflops": round(value * 3 * fpc / 1e12, 1),
             "model_frac_of_bf16_peak": round(value * 3 * fpc / 1e12 / (BF16_DENSE_PEAK_TFLOPS * world), 4),
             "roofline": roofline,
+            "selfcheck": "skipped" if (args.no_selfcheck or args.dtype != "bf16") else "passed",
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

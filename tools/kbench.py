@@ -65,6 +65,10 @@ def gemm_section(M, dev, bf):
     dy = torch.randn(M, 768, device=dev, dtype=bf); w2 = torch.randn(768, 3072, device=dev, dtype=bf)
     t = timeit(lambda: ops.gemm(dy, w2, trans_b=True, aux=aux, out=out, epilogue=ops.EPI_DGELU | ops.EPI_DROPOUT, drop_p=0.3, drop_seed=5))
     print(f"ffn2 dgrad dgelu+dropout: {t*1e3:8.3f} ms {2*M*3072*768/t/1e12:7.1f} TF/s")
+    t = timeit(lambda: ops.gemm(a, b, bias=bias, aux=aux, out=out, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=0.3, drop_seed=5))
+    print(f"ffn1 gelu+AUX_GRAD+dropout: {t*1e3:8.3f} ms {2*M*3072*768/t/1e12:7.1f} TF/s")
+    t = timeit(lambda: ops.gemm(dy, w2, trans_b=True, aux=aux, out=out, epilogue=ops.EPI_MULAUX))
+    print(f"ffn2 dgrad MULAUX: {t*1e3:8.3f} ms {2*M*3072*768/t/1e12:7.1f} TF/s")
     res = torch.randn(M, 768, device=dev, dtype=bf); w3 = torch.randn(768, 3072, device=dev, dtype=bf); b3 = torch.randn(768, device=dev, dtype=bf)
     o3 = torch.empty(M, 768, device=dev, dtype=bf)
     t = timeit(lambda: ops.gemm(out, w3, bias=b3, residual=res, out=o3, epilogue=ops.EPI_DROPOUT, drop_p=0.4, drop_seed=5))
