@@ -43,6 +43,7 @@ class GradientBucketer:
         self.sync_this_backward = True
         self.aligned = flat.numel() == sum((p.numel() + 63) // 64 * 64 for p in self.params)
         self._index = {id(p): i for i, p in enumerate(self.params)}
+        self.bucket_ends = []
         self._assign_views(self.params)
         self.reset()
 
@@ -61,20 +62,36 @@ class GradientBucketer:
 
     def finalize_layout(self):
         """Re-lay the arena out in observed completion order (parameters never reported go last).
-        Gradient values already in the arena are carried over to the new positions."""
+        Gradient values already in the arena are carried over to the new positions.
+        Every rank must end up with the SAME layout and the same bucket boundaries — a rank whose first batch
+        had no image comment observes a different order — so rank 0's order is broadcast and adopted by all."""
         seen = set()
-        ordered = []
+        order_idx = []
         for pid in self.order_observed:
             if pid not in seen and pid in self._index:
                 seen.add(pid)
-                ordered.append(self.params[self._index[pid]])
-        ordered += [p for p in self.params if id(p) not in seen]
+                order_idx.append(self._index[pid])
+        order_idx += [i for i, p in enumerate(self.params) if id(p) not in seen]
+        if self.world > 1:
+            t = torch.tensor(order_idx, dtype=torch.int64, device=self.flat.device)
+            dist.broadcast(t, 0, group=self.pg)
+            order_idx = [int(i) for i in t.tolist()]
+        ordered = [self.params[i] for i in order_idx]
         old = self.flat.clone()
         old_slots = {pid: off for pid, off, _ in self.slots}
         self._assign_views(ordered)
         for p in ordered:
             off = old_slots[id(p)]
             p.main_grad.view(-1).copy_(old[off:off + p.numel()])
+        # static buckets: whole slots, at least bucket_elems each, the same on every rank
+        self.bucket_ends = []
+        start = 0
+        for _, off, span in self.slots:
+            if off + span - start >= self.bucket_elems:
+                self.bucket_ends.append(off + span)
+                start = off + span
+        if not self.bucket_ends or self.bucket_ends[-1] != self.flat.numel():
+            self.bucket_ends.append(self.flat.numel())
         self.layout_final = True
         self.reset()
 
@@ -83,6 +100,7 @@ class GradientBucketer:
         self.ready = [False] * len(self.slots)
         self.cursor = 0            # slots [0, cursor) are final
         self.launched = 0          # elements [0, launched) already handed to all_reduce
+        self.next_bucket = 0       # index into bucket_ends of the next bucket to launch
         self.handles = []
 
     def on_params_ready(self, params):
@@ -99,9 +117,12 @@ class GradientBucketer:
         while self.cursor < len(self.slots) and self.ready[self.cursor]:
             self.cursor += 1
         if self.active and self.layout_final:
+            # launch every static bucket that is now entirely final — the SEQUENCE of collectives (sizes and
+            # order) is fixed by bucket_ends, only its timing depends on this rank's batch
             end = self.slots[self.cursor - 1][1] + self.slots[self.cursor - 1][2] if self.cursor else 0
-            if end - self.launched >= self.bucket_elems:
-                self._launch(self.launched, end)
+            while self.next_bucket < len(self.bucket_ends) and self.bucket_ends[self.next_bucket] <= end:
+                self._launch(self.launched, self.bucket_ends[self.next_bucket])
+                self.next_bucket += 1
 
     def _launch(self, a: int, b: int):
         if b <= a:
@@ -121,7 +142,12 @@ class GradientBucketer:
         """End of backward: reduce what is left, wait, scale by 1 / global sample size.
         ``scalars`` (fp32 vector: loss, sample_size, counters...) is summed over ranks in place."""
         if self.active:
-            self._launch(self.launched, self.flat.numel())
+            if self.layout_final:
+                while self.next_bucket < len(self.bucket_ends):     # buckets whose parameters never reported
+                    self._launch(self.launched, self.bucket_ends[self.next_bucket])
+                    self.next_bucket += 1
+            else:
+                self._launch(0, self.flat.numel())                  # first step: one all-reduce of the whole arena
             if scalars is not None:
                 self.handles.append(dist.all_reduce(scalars, group=self.pg, async_op=True) if self.comm_stream is None
                                     else self._scalar_reduce(scalars))

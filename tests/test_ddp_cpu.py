@@ -33,6 +33,10 @@ def _worker(rank, world, port, q):
         flat = torch.zeros(sum(p.numel() for p in train))
         b = GradientBucketer(params, flat, bucket_bytes=4 * 600)      # small buckets → several all-reduces
         fire_order = [[train[4], train[2]], [train[3]], [train[0], train[1]]]   # train[5] (the [300] vector) never reports
+        if rank == 1:
+            # this rank's batches have no image comments: one group never reports and the order differs — the
+            # arena layout and the sequence of collectives must still be the ones rank 0 derives
+            fire_order = [[train[3]], [train[4], train[2]]]
         results = []
         for step in range(3):
             flat.zero_()
@@ -61,9 +65,10 @@ def _worker(rank, world, port, q):
                 torch.testing.assert_close(p.main_grad, exp / tot, atol=1e-6, rtol=1e-6)
             assert abs(float(scal[1]) - tot) < 1e-6 and abs(float(scal[0]) - sum(1.5 + r for r in range(world))) < 1e-6
             results.append(True)
-        # after re-layout the arena starts with the first-finished group and ends with the silent parameter
+        # after re-layout the arena starts with rank 0's first-finished group and ends with the silent parameter
         first = b.slots[0][0]
         assert first == id(train[4]) and b.slots[-1][0] == id(train[5])
+        assert len(b.bucket_ends) >= 2 and b.bucket_ends[-1] == flat.numel()
         q.put((rank, "ok", len(results)))
     except Exception as e:  # noqa: BLE001
         import traceback
