@@ -98,7 +98,11 @@ class GemmTimer:
             s.record()
             out = raw(a, b, trans_a=trans_a, trans_b=trans_b, **kw)
             e.record()
-            timer.records.append((s, e, 2.0 * M * N * K))
+            nbytes = 2.0 * (M * K + N * K) + out.numel() * out.element_size()      # operands read once + C written once
+            for extra in ("aux", "residual"):
+                if kw.get(extra) is not None:
+                    nbytes += 2.0 * M * N
+            timer.records.append((s, e, 2.0 * M * N * K, nbytes))
             return out
 
         ops.gemm = timed
@@ -107,10 +111,10 @@ class GemmTimer:
     def summary(self):
         if not self.records:
             return None
-        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
-        fl = sum(f for _, _, f in self.records)
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        fl = sum(r[2] for r in self.records)
         return dict(launches=len(self.records), total_ms=ms, flops=fl, tflops=fl / (ms * 1e-3) / 1e12,
-                    avg_us=ms * 1e3 / len(self.records))
+                    avg_us=ms * 1e3 / len(self.records), bytes=sum(r[3] for r in self.records))
 
 
 def cpu_baseline(args):
@@ -307,10 +311,20 @@ def main():
                                 G=args.num_fusion_layers + 1, N=args.nodes, rho=args.image_frac)
         gs = timer.summary()
         roofline = None
+        traffic, traffic_src = None, None
+        try:                                       # HBM-side bytes per launch of the GEMM family, from the committed PMC passes
+            import glob
+            cand = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+            if cand:
+                traffic = json.load(open(cand[-1]))["gemm_family_bytes_per_launch"]
+                traffic_src = "profiles/" + os.path.basename(cand[-1])
+        except (OSError, KeyError, ValueError):
+            pass
         if gs:
-            roofline = dict(bound="mfma", kernel="gemm_bf16_tile256 (bf16 MFMA tile GEMM family: 256x256 / 256x128 / 128x128)", achieved=round(gs["tflops"], 1),
+            roofline = dict(bound="mfma", kernel="gemm_bf16_pp256p / gemm_bf16_pp256 (bf16 MFMA tile GEMM family: persistent 256x256 ping-pong, split-K 256x256, 128x128)", achieved=round(gs["tflops"], 1),
                             peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(gs["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4),
-                            traffic=None, launches=gs["launches"], avg_launch_us=round(gs["avg_us"], 1),
+                            traffic=traffic, traffic_unit="bytes per launch (fabric-side FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)", traffic_source=traffic_src,
+                            algorithmic_bytes_per_launch=round(gs["bytes"] / gs["launches"]) if gs.get("bytes") else None, launches=gs["launches"], avg_launch_us=round(gs["avg_us"], 1),
                             share_of_step=round(gs["total_ms"] * 1e-3 / dt, 3))
         out = {
             "metric": "discussion-tree comments/sec fwd+bwd", "value": round(value, 1), "unit": "comments/s",
