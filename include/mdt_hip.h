@@ -138,8 +138,12 @@ typedef struct {
   const void* virt;
   const uint8_t* key_pad;
   int num_spatial;
-  float drop_p;              /* attention-probability dropout (0 = off); counter ((s*H + h)*S + q)*S + key */
+  float drop_p;              /* attention-probability dropout (0 = off); counter ((s*H + h)*S + q)*S2 + key, S2 = S rounded up to even */
   uint64_t drop_seed;
+  const int32_t* seq_offsets; /* NULL, or i32[nseq + 1]: RAGGED sequences — sequence s is the S_s = off[s+1] - off[s] <= S
+                                 consecutive rows starting at row off[s] (seq_stride unused, pos_stride must be 1, no masks /
+                                 biases: every packed token is valid).  S stays the bound that sizes lse [nseq,H,S] and the
+                                 dropout counters.  This is how padded token positions of a comment batch are never computed. */
 } mdt_attn_fwd_args;
 int mdt_attention_fwd(void* stream, const mdt_attn_fwd_args* a);
 
@@ -184,6 +188,12 @@ int mdt_row_scatter_add_f32(void* stream, int dtype, int64_t nrows, int D, float
 int mdt_bert_embed_sum(void* stream, int dtype, int64_t M, int L, const int32_t* ids, const int32_t* types,
                        const void* word, const void* pos, const void* type, int D,
                        void* out, int64_t ldo, int64_t out_seq_stride, int64_t out_off);
+
+/* Ragged form of the same sum: one output row per VALID token (padded positions are never materialised);
+ * out[r,:] = word[ids[r]] + pos[pos_ids[r]] + type[types[r]]. */
+int mdt_bert_embed_rows(void* stream, int dtype, int64_t rows, const int32_t* ids, const int32_t* types,
+                        const int32_t* pos_ids, const void* word, const void* pos, const void* type, int D,
+                        void* out, int64_t ldo);
 
 /* ViT patch gather (Conv2d k=s=p is a pure re-index, modules/multigraphormer_graph_encoder.py:333):
  * cols[(i*np + py*gw + px), c*p*p + dy*p + dx] = img[i, c, py*p+dy, px*p+dx]  (img fp32 → T). */

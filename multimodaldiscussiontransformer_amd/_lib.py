@@ -28,7 +28,7 @@ class AttnFwdArgs(C.Structure):
         ("qkv", _vp), ("ld_qkv", _i64), ("out", _vp), ("ld_out", _i64), ("lse", _vp),
         ("key_mask", _vp), ("dense_bias", _vp), ("attn_bias", _vp), ("spatial_pos", _vp),
         ("sp_table", _vp), ("virt", _vp), ("key_pad", _vp), ("num_spatial", _i),
-        ("drop_p", _f), ("drop_seed", C.c_uint64),
+        ("drop_p", _f), ("drop_seed", C.c_uint64), ("seq_offsets", _vp),
     ]
 
 
@@ -57,6 +57,7 @@ _SIGS = {
                        _vp, _i64, _vp, _i64, _i64, _i64, _f, _i], _i),
     "mdt_row_scatter_add_f32": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _vp, _i64, _i64, _i64], _i),
     "mdt_bert_embed_sum": ([_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i64], _i),
+    "mdt_bert_embed_rows": ([_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64], _i),
     "mdt_vit_patchify": ([_vp, _i, _i, _i, _i, _i, _vp, _vp, _i64], _i),
     "mdt_vit_assemble": ([_vp, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64], _i),
     "mdt_graph_node_feature": ([_vp, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64], _i),

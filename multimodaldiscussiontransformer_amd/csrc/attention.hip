@@ -103,9 +103,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
   const mdt_attn_fwd_args& a = P.f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, seq = blockIdx.y;
-  const int S = a.S, D = a.H * HD;
+  const int SL = a.S, D = a.H * HD;                      // SL: lse / dropout-counter geometry
+  const int S = a.seq_offsets ? a.seq_offsets[seq + 1] - a.seq_offsets[seq] : a.S;   // this sequence's length
   constexpr int s_pad32 = (NT * 16 + 31) & ~31;  // key range every tile loop covers
-  const int64_t row0 = (int64_t)seq * a.seq_stride;
+  const int64_t row0 = a.seq_offsets ? (int64_t)a.seq_offsets[seq] : (int64_t)seq * a.seq_stride;
   const T* qkv = (const T*)a.qkv + row0 * a.ld_qkv + h * HD;
   const int64_t tld = a.pos_stride * a.ld_qkv;  // row stride between consecutive positions
 
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
       sum[r] = row16_sum(sum[r]);
       const int q = q0 + (lane >> 4) * 4 + r;
       if ((lane & 15) == 0 && q < S && a.lse)
-        a.lse[((int64_t)seq * a.H + h) * S + q] = (sum[r] > 0.f) ? mx[r] + __logf(sum[r]) : -INFINITY;
+        a.lse[((int64_t)seq * a.H + h) * SL + q] = (sum[r] > 0.f) ? mx[r] + __logf(sum[r]) : -INFINITY;
       sum[r] = (sum[r] > 0.f) ? 1.0f / sum[r] : 0.f;
     }
     const int drop_bh = seq * a.H + h;   // counters: attention_common.hpp
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
         float pv = sc[t][r] * sum[r];
         if constexpr (DROP) {
           const int q = q0 + (lane >> 4) * 4 + r, key = t * 16 + (lane & 15);
-          pv *= attn_drop_scale(P.drop, drop_bh, S, q, key);
+          pv *= attn_drop_scale(P.drop, drop_bh, SL, q, key);
         }
         scratch[((lane >> 4) * 4 + r) * sld + t * 16 + (lane & 15)] = from_f32<T>(pv);
       }
@@ -237,9 +238,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams P) {
   const mdt_attn_fwd_args& a = P.f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, seq = blockIdx.y;
-  const int S = a.S, D = a.H * HD;
+  const int SL = a.S, D = a.H * HD;                      // SL: lse / dropout-counter geometry
+  const int S = a.seq_offsets ? a.seq_offsets[seq + 1] - a.seq_offsets[seq] : a.S;   // this sequence's length
   constexpr int s_pad32 = (NT * 16 + 31) & ~31;  // key range every tile loop covers
-  const int64_t row0 = (int64_t)seq * a.seq_stride;
+  const int64_t row0 = a.seq_offsets ? (int64_t)a.seq_offsets[seq] : (int64_t)seq * a.seq_stride;
   const T* qkv = (const T*)a.qkv + row0 * a.ld_qkv + h * HD;
   const T* dout = (const T*)P.dout + row0 * P.ld_dout + h * HD;
   T* dqkv = (T*)P.dqkv + row0 * P.ld_dqkv + h * HD;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams P) {
   const Src<T> srcX{scratch, sld, 16};
 
   for (int i = tid; i < s_pad32; i += 256) {
-    s_lse[i] = (i < S) ? a.lse[((int64_t)seq * a.H + h) * S + i] : 0.f;
+    s_lse[i] = (i < S) ? a.lse[((int64_t)seq * a.H + h) * SL + i] : 0.f;
     s_delta[i] = 0.f;
   }
   for (int i = tid; i < nhist; i += 256) s_hist[i] = 0.f;
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams P) {
           const float l = s_lse[q];
           const float p = (v == -INFINITY || l == -INFINITY || !qok) ? 0.f : __expf(v - l);
           sc[t][r] = p;
-          if constexpr (DROP) dp[t][r] *= attn_drop_scale(P.drop, drop_bh, S, q, key);   // dP = dD * M / (1-p)
+          if constexpr (DROP) dp[t][r] *= attn_drop_scale(P.drop, drop_bh, SL, q, key);   // dP = dD * M / (1-p)
           del[r] += p * dp[t][r];
         }
       }
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams P) {
           float ds = dp[t][r];
           float pd = p;
           if constexpr (DROP) {
-            const float m = attn_drop_scale(P.drop, drop_bh, S, qc, key);
+            const float m = attn_drop_scale(P.drop, drop_bh, SL, qc, key);
             ds *= m;                          // dP^T = dD^T * M / (1-p)
             pd *= m;                          // D^T  = P^T * M / (1-p)
           }
@@ -598,6 +600,9 @@ static int check_args(const mdt_attn_fwd_args& a) {
     MDT_CHECK_ARG(a.ld_qkv % 8 == 0 && ((uintptr_t)a.qkv & 15) == 0, "attention(bf16): qkv must be 16-byte aligned rows");
   if (a.attn_bias) MDT_CHECK_ARG(a.spatial_pos && a.sp_table && a.virt && a.num_spatial > 0, "attention: incomplete structural bias");
   MDT_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f, "attention: dropout p=%f out of [0,1)", a.drop_p);
+  if (a.seq_offsets)
+    MDT_CHECK_ARG(a.pos_stride == 1 && !a.key_mask && !a.key_pad && !a.dense_bias && !a.attn_bias,
+                  "attention: ragged sequences (seq_offsets) take no masks / biases and need pos_stride == 1");
   MDT_CHECK_ARG(a.drop_p == 0.f || (uint64_t)a.nseq * a.H * a.S * (a.S + 1) < (1ull << 32),
                 "attention: dropout counters are 32-bit (nseq*H*S*(S+1) must stay below 2^32)");
   return MDT_OK;

@@ -78,14 +78,19 @@ __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(AttnParams P) {
   const mdt_attn_fwd_args& a = P.f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, seq = blockIdx.y;
-  const int S = a.S, D = a.H * HD;
-  const int64_t row0 = (int64_t)seq * a.seq_stride;
+  const int SL = a.S, D = a.H * HD;                      // SL: lse / dropout-counter geometry
+  const int S = a.seq_offsets ? a.seq_offsets[seq + 1] - a.seq_offsets[seq] : a.S;   // this sequence's length
+  const int64_t row0 = a.seq_offsets ? (int64_t)a.seq_offsets[seq] : (int64_t)seq * a.seq_stride;
   const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * a.ld_qkv + h * HD;
   const int64_t tld = a.pos_stride * a.ld_qkv;
   bf16_t* imgK = (bf16_t*)smem;
   bf16_t* imgV = imgK + S_PAD * V2_LD;
   float* s_kb = (float*)(imgV + S_PAD * V2_LD);   // key-only bias (0 / -inf), [S_PAD]
   BiasCtx bc{seq, h, S, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
+  // Ragged sequences: key tiles past this sequence's length are staged as zeros, their scores come out of the
+  // (unguarded: a guard there costs the compiler 80 registers) MFMA loop as exact zeros and every later
+  // per-element stage skips them, so they cost LDS reads and idle MFMA slots but no VALU work.
+  const int ntk = (S + 15) >> 4;
   v2_stage<HD>(imgK, qkv + D, tld, S, S_PAD, tid);
   v2_stage<HD>(imgV, qkv + 2 * D, tld, S, S_PAD, tid);
   for (int i = tid; i < S_PAD; i += 256) s_kb[i] = key_only_bias<bf16_t>(bc, i);
@@ -105,15 +110,17 @@ __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(AttnParams P) {
 #pragma unroll
     for (int t = 0; t < 2 * NP; ++t) sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int ks = 0; ks < HD / 32; ++ks) {
         sc[t] = mfma_bf16(v2_frag_lds(imgK, t * 16, ks * 32, lane), fq[ks], sc[t]);
         if (ks == HD / 32 - 1 && (t & 1)) __builtin_amdgcn_sched_barrier(0);   // bound operand prefetch depth (registers)
       }
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+      if (t >= ntk) continue;
       const f32x4 kb = *(const f32x4*)(s_kb + t * 16 + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -130,21 +137,24 @@ __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(AttnParams P) {
     const float mxc = (mx == -INFINITY) ? 0.f : mx;   // fully masked row: every exp2 below is exp2(-inf) = 0
     float sum = 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      if (t >= ntk) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float e = __builtin_amdgcn_exp2f(sc[t][r] - mxc);
         sc[t][r] = e;
         sum += e;
       }
+    }
     sum = col_sum(sum);
-    if (g == 0 && q < S) a.lse[((int64_t)seq * a.H + h) * S + q] = (sum > 0.f) ? (mxc + __builtin_amdgcn_logf(sum)) * LN2 : -INFINITY;
+    if (g == 0 && q < S) a.lse[((int64_t)seq * a.H + h) * SL + q] = (sum > 0.f) ? (mxc + __builtin_amdgcn_logf(sum)) * LN2 : -INFINITY;
     float inv = (sum > 0.f) ? __builtin_amdgcn_rcpf(sum) : 0.f;
     if constexpr (DROP) {
       inv *= P.drop.inv_keep;
-      const uint32_t rp = attn_row_pairs(drop_bh, S, qc) + 2 * g;
+      const uint32_t rp = attn_row_pairs(drop_bh, SL, qc) + 2 * g;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
+        if (t >= ntk) continue;
         const uint32_t w0 = drop_mix((rp + 8 * t) ^ P.drop.key), w1 = drop_mix((rp + 8 * t + 1) ^ P.drop.key);
         sc[t][0] = drop_keep_lo(P.drop, w0) ? sc[t][0] : 0.f;
         sc[t][1] = drop_keep_hi(P.drop, w0) ? sc[t][1] : 0.f;
@@ -157,6 +167,7 @@ __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(AttnParams P) {
     for (int d = 0; d < ND; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi) {
+      if (2 * pi >= ntk) continue;
       const bf16x8 fp = v2_pack(sc[2 * pi], sc[2 * pi + 1]);
 #pragma unroll
       for (int d = 0; d < ND; ++d) o[d] = mfma_bf16(v2_frag_tr(imgV, 2 * pi, d * 16, lane), fp, o[d]);
@@ -182,8 +193,9 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
   const mdt_attn_fwd_args& a = P.f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, seq = blockIdx.y;
-  const int S = a.S, D = a.H * HD;
-  const int64_t row0 = (int64_t)seq * a.seq_stride;
+  const int SL = a.S, D = a.H * HD;                      // SL: lse / dropout-counter geometry
+  const int S = a.seq_offsets ? a.seq_offsets[seq + 1] - a.seq_offsets[seq] : a.S;   // this sequence's length
+  const int64_t row0 = a.seq_offsets ? (int64_t)a.seq_offsets[seq] : (int64_t)seq * a.seq_stride;
   const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * a.ld_qkv + h * HD;
   const bf16_t* dout = (const bf16_t*)P.dout + row0 * P.ld_dout + h * HD;
   bf16_t* dqkv = (bf16_t*)P.dqkv + row0 * P.ld_dqkv + h * HD;
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
   v2_stage<HD>(img1, qkv + 2 * D, tld, S, S_PAD, tid);  // V
   for (int i = tid; i < S_PAD; i += 256) {
     s_kb[i] = key_only_bias<bf16_t>(bc, i);
-    s_lse[i] = (i < S) ? a.lse[((int64_t)seq * a.H + h) * S + i] : -INFINITY;
+    s_lse[i] = (i < S) ? a.lse[((int64_t)seq * a.H + h) * SL + i] : -INFINITY;
     s_delta[i] = 0.f;
   }
   for (int i = tid; i < nhist; i += 256) s_hist[i] = 0.f;
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
         if (STRUCT && key < S) v += pair_bias<bf16_t, STRUCT>(bc, qc, key);
         const float p = (v == -INFINITY || l == -INFINITY || !qok) ? 0.f : __expf(v - l);
         sc[t][r] = p;
-        if constexpr (DROP) dp[t][r] *= attn_drop_scale(P.drop, drop_bh, S, q, key);
+        if constexpr (DROP) dp[t][r] *= attn_drop_scale(P.drop, drop_bh, SL, q, key);
         del += p * dp[t][r];
       }
     del = col_sum(del);
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
         float ds = dp[t][r];
         float pd = p;
         if constexpr (DROP) {
-          const float m = attn_drop_scale(P.drop, drop_bh, S, qc, key);
+          const float m = attn_drop_scale(P.drop, drop_bh, SL, qc, key);
           ds *= m;
           pd *= m;
         }
@@ -389,8 +401,9 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
   const mdt_attn_fwd_args& a = P.f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, seq = blockIdx.y;
-  const int S = a.S, D = a.H * HD;
-  const int64_t row0 = (int64_t)seq * a.seq_stride;
+  const int SL = a.S, D = a.H * HD;                      // SL: lse / dropout-counter geometry
+  const int S = a.seq_offsets ? a.seq_offsets[seq + 1] - a.seq_offsets[seq] : a.S;   // this sequence's length
+  const int64_t row0 = a.seq_offsets ? (int64_t)a.seq_offsets[seq] : (int64_t)seq * a.seq_stride;
   const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * a.ld_qkv + h * HD;
   const bf16_t* dout = (const bf16_t*)P.dout + row0 * P.ld_dout + h * HD;
   const bf16_t* outp = (const bf16_t*)a.out + row0 * a.ld_out + h * HD;
@@ -405,17 +418,18 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
   float* s_hist = s_delta + s_pad;
   const int nhist = STRUCT ? ((a.num_spatial + 1 + 3) & ~3) : 0;
   BiasCtx bc{seq, h, S, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
-  v2_stage<HD>(img0, qkv + D, tld, S, s_pad, tid);      // K
-  v2_stage<HD>(img1, qkv + 2 * D, tld, S, s_pad, tid);  // V
+  const int s_live = (S + 63) & ~63;                    // rows this (possibly ragged) sequence really uses, in 64-key chunks
+  v2_stage<HD>(img0, qkv + D, tld, S, s_live, tid);      // K
+  v2_stage<HD>(img1, qkv + 2 * D, tld, S, s_live, tid);  // V
   // s_lse holds lse * log2(e) (+inf for rows without a finite lse, so every p of such a row is exp2(-inf) = 0);
   // s_delta holds delta * (1 - p_drop): the 1 / (1 - p_drop) factor of the dropout mask is folded out of
   // dS and dV and applied once to the outputs.
   const float ik = DROP ? P.drop.inv_keep : 1.0f, rik = 1.0f / ik;
-  for (int i = tid; i < s_pad; i += 256) {
+  for (int i = tid; i < s_live; i += 256) {
     s_kb[i] = key_only_bias<bf16_t>(bc, i);
     float l = -INFINITY, de = 0.f;
     if (i < S) {
-      l = a.lse[((int64_t)seq * a.H + h) * S + i];
+      l = a.lse[((int64_t)seq * a.H + h) * SL + i];
 #pragma unroll
       for (int c8 = 0; c8 < HD / 8; ++c8) {
         const bf16x8 o = *(const bf16x8*)(outp + i * old_ + c8 * 8);
@@ -430,11 +444,11 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
   for (int i = tid; i < nhist; i += 256) s_hist[i] = 0.f;
   __syncthreads();
   const int drop_bh = seq * a.H + h;   // counters: attention_common.hpp
-  const uint32_t s2h = (uint32_t)((S + 1) >> 1);
+  const uint32_t s2h = (uint32_t)((SL + 1) >> 1);
   const float scale2 = a.scale * LOG2E;
   const int g = lane >> 4, c = lane & 15;
   const int n_t = (S + 15) >> 4;
-  const int n_chunk = s_pad >> 6;           // 64-wide chunks (s_pad is a multiple of 64)
+  const int n_chunk = s_live >> 6;          // 64-wide chunks
 
   // ------------------------------------------------------------------ pass A (queries on lanes)
   for (int qt = wave; qt < n_t; qt += 4) {
@@ -449,7 +463,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
       fo[ks] = v2_frag_glb(dout, dld, S, q0, ks * 32, lane);
     }
     const float l2 = s_lse[qc], del = s_delta[qc];
-    const uint32_t rp = attn_row_pairs(drop_bh, S, qc) + 2 * g;
+    const uint32_t rp = attn_row_pairs(drop_bh, SL, qc) + 2 * g;
     f32x4 dq[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -519,8 +533,8 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
     }
   }
   __syncthreads();   // K / V images are free
-  v2_stage<HD>(img0, qkv, tld, S, s_pad, tid);    // Q
-  v2_stage<HD>(img1, dout, dld, S, s_pad, tid);   // dO
+  v2_stage<HD>(img0, qkv, tld, S, s_live, tid);    // Q
+  v2_stage<HD>(img1, dout, dld, S, s_live, tid);   // dO
   if constexpr (STRUCT) {
     if (P.d_sp_table) {
       for (int i = tid; i <= a.num_spatial; i += 256) {
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
   // words; the neighbouring lane (key ^ 1) needs the same four words (other half), so each lane of the pair
   // computes two of them and they trade through one DPP quad swap each.
   const int odd = c & 1;
-  const uint32_t base_rp = (uint32_t)(drop_bh * S) * s2h;
+  const uint32_t base_rp = (uint32_t)(drop_bh * SL) * s2h;
   for (int kt = wave; kt < n_t; kt += 4) {
     const int key0 = kt * 16;
     const int key = key0 + c;

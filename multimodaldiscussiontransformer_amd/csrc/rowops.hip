@@ -111,6 +111,29 @@ __global__ __launch_bounds__(256) void bert_embed_sum_kernel(int64_t M, int L, c
   }
 }
 
+// ragged form: one packed row per VALID token, explicit position ids
+template <typename T>
+__global__ __launch_bounds__(256) void bert_embed_rows_kernel(int64_t rows, const int32_t* ids, const int32_t* types,
+                                                              const int32_t* pos_ids, const T* word, const T* pos, const T* type,
+                                                              int D, T* out, int64_t ldo) {
+  constexpr int VN = V16<T>::N;
+  typedef typename V16<T>::type vec;
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int64_t w = ids[r], t = types[r], l = pos_ids[r];
+  T* o = out + r * ldo;
+  for (int c = lane * VN; c < D; c += 64 * VN) {
+    const vec vw = *(const vec*)(word + w * D + c);
+    const vec vp = *(const vec*)(pos + l * D + c);
+    const vec vt = *(const vec*)(type + t * D + c);
+    vec ov;
+#pragma unroll
+    for (int j = 0; j < VN; ++j) ov[j] = from_f32<T>(to_f32((T)vw[j]) + to_f32((T)vt[j]) + to_f32((T)vp[j]));
+    *(vec*)(o + c) = ov;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void vit_patchify_kernel(int I, int C, int HW, int p, const float* img, T* cols,
                                                            int64_t ldc) {
@@ -299,6 +322,20 @@ extern "C" int mdt_bert_embed_sum(void* stream, int dtype, int64_t M, int L, con
   DISPATCH_T(dtype, K_, 0);
 #undef K_
   return check_launch("bert_embed_sum");
+}
+
+extern "C" int mdt_bert_embed_rows(void* stream, int dtype, int64_t rows, const int32_t* ids, const int32_t* types,
+                                   const int32_t* pos_ids, const void* word, const void* pos, const void* type, int D,
+                                   void* out, int64_t ldo) {
+  if (rows == 0) return MDT_OK;
+  MDT_CHECK_ARG(ids && types && pos_ids && word && pos && type && out, "bert_embed_rows: null pointer");
+  if (int e = vec_ok(dtype, D, ldo, out)) return e;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+#define K_(T, ...) hipLaunchKernelGGL((bert_embed_rows_kernel<T>), grid, 256, 0, st, rows, ids, types, pos_ids, (const T*)word, (const T*)pos, (const T*)type, D, (T*)out, ldo)
+  DISPATCH_T(dtype, K_, 0);
+#undef K_
+  return check_launch("bert_embed_rows");
 }
 
 extern "C" int mdt_vit_patchify(void* stream, int dtype, int I, int C, int HW, int p, const float* img, void* cols, int64_t ldc) {

@@ -64,10 +64,47 @@ class PackedBatch:
     targets: torch.Tensor       # i32[#lab]
     n_labels: int = 0
     extras: dict = field(default_factory=dict)
+    ragged: Optional["RaggedText"] = None      # valid-token packing (built on the host by pack_batch; lazily otherwise)
 
     @property
     def T(self):
         return self.N + 1
+
+
+@dataclass
+class RaggedText:
+    """Valid-token packing of the text side: only positions with attention_mask == 1 get a row.  The reference
+    pads every comment to L tokens and computes all of them (HF BERT with an additive mask); padded positions are
+    never attended to and never read by the head, so logits and every gradient are unchanged when they are simply
+    not computed (SURVEY.md §8 item 8 makes the same point for padded graph nodes)."""
+    rows: int                   # T0 = number of valid tokens in the batch
+    max_len: int                # longest comment (tokens)
+    offsets: torch.Tensor       # i32[M + 1]  first packed row of every comment
+    ids: torch.Tensor           # i32[T0]
+    types: torch.Tensor         # i32[T0]
+    pos: torch.Tensor           # i32[T0]     original position of the token in its comment (position-embedding index)
+    comment: torch.Tensor       # i32[T0]     comment index of the row
+
+
+def ragged_text(ids: torch.Tensor, types: torch.Tensor, mask: torch.Tensor, device=None, non_blocking=True) -> RaggedText:
+    """Build the packing from [M, L] id / type / mask matrices (host tensors in ``pack_batch``: no device sync;
+    device tensors in the compatibility path: one ``nonzero``)."""
+    M, Lq = ids.shape
+    valid = mask.reshape(-1) != 0
+    src = torch.nonzero(valid).flatten()
+    lens = (mask != 0).sum(1)
+    if int(lens.min()) < 1:
+        raise ValueError("a comment without any valid token cannot be packed")
+    off = torch.zeros(M + 1, dtype=torch.int64, device=ids.device)
+    off[1:] = torch.cumsum(lens, 0)
+    comment = torch.div(src, Lq, rounding_mode="floor")
+
+    def to(t):
+        t = t.to(torch.int32).contiguous()
+        return t if device is None else t.to(device, non_blocking=non_blocking)
+
+    return RaggedText(rows=int(src.numel()), max_len=int(lens.max()), offsets=to(off), ids=to(ids.reshape(-1)[src]),
+                      types=to(types.reshape(-1)[src]), pos=to(src - comment * Lq), comment=to(comment))
 
 
 def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_blocking=True) -> PackedBatch:
@@ -148,8 +185,15 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
         spatial_pos=bd["spatial_pos"], img_comment=to(img_comment), images=bd["x_images"],
         label_rows=to(label_rows), targets=to(torch.from_numpy(y.astype(np.int32))), n_labels=int(label_rows.numel()),
     )
+    pb.ragged = ragged_text(ids, types, tmask, device=device, non_blocking=non_blocking)   # host-side: no device sync
     bd["_packed"] = pb                             # lets model(**net_input) find the CSR view
     return pb
+
+
+def get_ragged(pb: PackedBatch) -> RaggedText:
+    if pb.ragged is None:
+        pb.ragged = ragged_text(pb.ids, pb.types, pb.text_mask)
+    return pb.ragged
 
 
 def packed_from_batched_data(bd: dict) -> PackedBatch:

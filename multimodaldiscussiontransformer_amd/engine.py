@@ -133,9 +133,11 @@ class AttnSpec:
     sp_table: Optional[torch.nn.Parameter] = None  # [num_spatial,H]
     virt: Optional[torch.nn.Parameter] = None      # [1,H]
     key_pad: Optional[torch.Tensor] = None         # u8[nseq,S]
+    seq_offsets: Optional[torch.Tensor] = None     # i32[nseq+1]: ragged sequences of at most S rows (no masks / biases)
 
     def kwargs(self):
         return dict(seq_stride=self.seq_stride, pos_stride=self.pos_stride, scale=self.scale, key_mask=self.key_mask,
+                    seq_offsets=self.seq_offsets,
                     dense_bias=self.dense_bias, attn_bias=self.attn_bias, spatial_pos=self.spatial_pos,
                     sp_table=None if self.sp_table is None else self.sp_table.data,
                     virt=None if self.virt is None else self.virt.data.view(-1), key_pad=self.key_pad)
@@ -374,6 +376,35 @@ def bert_embeddings(tape: Tape, ids, types, word, pos, typ) -> Var:
     return o
 
 
+def bert_embeddings_rows(tape: Tape, ids, types, pos_ids, word, pos, typ) -> Var:
+    """Ragged form of ``bert_embeddings``: one row per VALID token (ids / types / pos_ids i32[rows])."""
+    rows = ids.numel()
+    D = word.shape[1]
+    out = torch.empty(rows, D, dtype=word.dtype, device=word.device)
+    ops.bert_embed_rows(ids, types, pos_ids, word.data, pos.data, typ.data, out)
+    o = Var(out)
+
+    def bwd():
+        g = o.grad
+        o.grad = None
+        if g is None:
+            return
+        gw, gp, gt = tape.pgrad(word), tape.pgrad(pos), tape.pgrad(typ)
+        if gw is not None:
+            ops.row_scatter_add(gw, ids, g, rows)
+        if gp is not None:
+            ops.row_scatter_add(gp, pos_ids, g, rows)
+        if gt is not None:
+            assert typ.shape[0] == 2, "token-type gradient is implemented for type_vocab_size == 2"
+            tot = ops.colsum(g)
+            one = ops.colsum(g, row_weight=types)
+            ops.row_axpby(gt, 1, d_off=1, a=one.view(1, D), accumulate=True)
+            ops.row_axpby(gt, 1, d_off=0, a=tot.view(1, D), b=one.view(1, D), beta=-1.0, accumulate=True)
+
+    tape.record(bwd)
+    return o
+
+
 def vit_embeddings(tape: Tape, images, proj_w, proj_b, cls, pos, patch: int) -> Var:
     """Conv2d(k = s = patch) as a patch gather + one GEMM, then [CLS] and position add."""
     I = images.shape[0]
@@ -442,6 +473,38 @@ def expand_sequences(tape: Tape, x: Var, nseq: int, s_in: int, n_front: int, fro
     return o
 
 
+def expand_rows(tape: Tape, x: Var, rows_out: int, body_idx, front_idx, n_front: int, front: torch.nn.Parameter) -> Var:
+    """Index-driven ``expand_sequences`` for the text side (padded or ragged layout alike): row r of ``x`` goes to
+    row ``body_idx[r]`` of the [rows_out, D] result, and row ``front_idx[k]`` receives learned bottleneck token
+    ``k % n_front`` (modules/multigraphormer_graph_encoder.py:339)."""
+    D = x.data.shape[1]
+    rows_in = x.data.shape[0]
+    nfront = front_idx.numel()
+    assert rows_in + nfront == rows_out, "expand_rows: body and front rows must tile the output exactly"
+    out = torch.empty(rows_out, D, dtype=x.data.dtype, device=x.data.device)
+    ops.row_axpby(out, rows_in, di=body_idx, a=x.data)
+    ops.row_axpby(out, nfront, di=front_idx, a=front.data, a_inner=n_front, a_stride=0, a_off=0)
+    o = Var(out)
+
+    def bwd():
+        g = o.grad
+        o.grad = None
+        if g is None:
+            return
+        gf = tape.pgrad(front)
+        if gf is not None:
+            fr = torch.empty(nfront, D, dtype=g.dtype, device=g.device)
+            ops.row_axpby(fr, nfront, a=g, ai=front_idx)
+            ops.colsum(fr.view(nfront // n_front, n_front * D), out=gf.view(-1))
+        if x.needs_grad:
+            dx = torch.empty_like(x.data)
+            ops.row_axpby(dx, rows_in, a=g, ai=body_idx)
+            tape.add_grad(x, dx)
+
+    tape.record(bwd)
+    return o
+
+
 def rows_mix(tape: Tape, dst: Var, src: Var, nrows: int, *, alpha: float, beta: float, d_idx=None, d_map=(1, 1, 0),
              s_idx=None, s_map=(1, 1, 0)) -> Var:
     """In place: dst[dr] = alpha * src[sr] + beta * dst[dr] for ``nrows`` row pairs.
@@ -502,14 +565,15 @@ def graph_node_features(tape: Tape, text: Var, text_row_of_node, in_degree, out_
     return o
 
 
-def classifier_head(tape: Tape, text: Var, M: int, St: int, nb: int, pool_w, pool_b, cls_w, cls_b, p_drop: float = 0.0) -> Var:
+def classifier_head(tape: Tape, text: Var, M: int, cls_rows, bn0_rows, pool_w, pool_b, cls_w, cls_b, p_drop: float = 0.0) -> Var:
     """models/multi_modal_discussion_transformer.py:265-274: the SAME pooler (dense + tanh on
     token 0) and classifier are applied to the text sequence ([CLS], row nb of each comment)
-    and to the bottleneck sequence (bottleneck token 0, row 0); logits are their mean."""
+    and to the bottleneck sequence (bottleneck token 0, row 0); logits are their mean.
+    ``cls_rows`` / ``bn0_rows``: i32[M] rows of [CLS] / bottleneck token 0 of every comment in ``text``."""
     D = text.data.shape[1]
     rows = torch.empty(2 * M, D, dtype=text.data.dtype, device=text.data.device)
-    ops.row_axpby(rows, M, d_off=0, a=text.data, a_stride=St, a_off=nb)
-    ops.row_axpby(rows, M, d_off=M, a=text.data, a_stride=St, a_off=0)
+    ops.row_axpby(rows, M, d_off=0, a=text.data, ai=cls_rows)
+    ops.row_axpby(rows, M, d_off=M, a=text.data, ai=bn0_rows)
     pre = ops.gemm(rows, pool_w.data, bias=pool_b.data)
     pooled = ops.tanh_fwd(pre)
     seed = tape.next_seed()
@@ -537,8 +601,8 @@ def classifier_head(tape: Tape, text: Var, M: int, St: int, nb: int, pool_w, poo
         if text.needs_grad:
             drows = ops.gemm(dpre, pool_w.data, trans_b=True)
             gt = tape.grad_buf(text)
-            ops.row_axpby(gt, M, d_stride=St, d_off=nb, a=drows, a_off=0, accumulate=True)
-            ops.row_axpby(gt, M, d_stride=St, d_off=0, a=drows, a_off=M, accumulate=True)
+            ops.row_axpby(gt, M, di=cls_rows, a=drows, a_off=0, accumulate=True)
+            ops.row_axpby(gt, M, di=bn0_rows, a=drows, a_off=M, accumulate=True)
         if tape.on_params_ready:
             tape.on_params_ready([pool_w, pool_b, cls_w, cls_b])
 
@@ -560,6 +624,25 @@ def take_rows(tape: Tape, src: Var, nrows: int, s_map=(1, 1, 0), s_idx=None) -> 
             return
         gs = tape.grad_buf(src)
         ops.row_axpby(gs, nrows, di=s_idx, d_inner=si, d_stride=ss, d_off=so, a=g, accumulate=True)
+
+    tape.record(bwd)
+    return o
+
+
+def scatter_rows(tape: Tape, src: Var, rows_out: int, d_idx, s_idx) -> Var:
+    """out = zeros[rows_out, D]; out[d_idx[r]] = src[s_idx[r]] (ragged rows back into the reference's padded shape)."""
+    n = d_idx.numel()
+    out = torch.zeros(rows_out, src.data.shape[1], dtype=src.data.dtype, device=src.data.device)
+    ops.row_axpby(out, n, di=d_idx, a=src.data, ai=s_idx)
+    o = Var(out)
+
+    def bwd():
+        g = o.grad
+        o.grad = None
+        if g is None or not src.needs_grad:
+            return
+        gs = tape.grad_buf(src)
+        ops.row_axpby(gs, n, di=s_idx, a=g, ai=d_idx, accumulate=True)
 
     tape.record(bwd)
     return o

@@ -157,7 +157,8 @@ class GraphormerEncoder(nn.Module):
 
         def run(tape):
             text, glob = ge._fwd(tape, pb)
-            logits = E.classifier_head(tape, text, pb.M, nb + pb.L, nb, ge.text_pooler.dense.weight,
+            ix = ge._indices(pb)
+            logits = E.classifier_head(tape, text, pb.M, ix["cls_rows"], ix["bn0_rows"], ge.text_pooler.dense.weight,
                                        ge.text_pooler.dense.bias, ge.node_classifier.weight, ge.node_classifier.bias,
                                        p_drop=p_head)
             return logits, glob

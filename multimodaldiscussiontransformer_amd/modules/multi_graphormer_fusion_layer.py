@@ -40,15 +40,16 @@ class GraphFusionLayer(nn.Module):
     def live_parameters(self):
         return list(self.bert_encoder.parameters()) + list(self.vit_encoder.parameters())
 
-    def _fwd(self, tape, text: E.Var, vit: Optional[E.Var], M: int, St: int, I: int, Sv: int, text_mask_u8,
+    def _fwd(self, tape, text: E.Var, vit: Optional[E.Var], M: int, text_spec: dict, I: int, Sv: int,
              img_text_bn_rows, vit_bn_rows):
-        """text [M*St, D], vit [I*Sv, D] or None.  ``img_text_bn_rows`` / ``vit_bn_rows``: i32[I*nb]
-        row indices of the bottleneck tokens of image comments in the text / image buffers."""
+        """text [rows, D] (padded: M*(nb+L) rows + key mask; ragged: valid tokens only + sequence offsets — both
+        described by ``text_spec`` = AttnSpec keywords), vit [I*Sv, D] or None.  ``img_text_bn_rows`` /
+        ``vit_bn_rows``: i32[I*nb] row indices of the bottleneck tokens of image comments in the text / image buffers."""
         nb = self.num_bottle_neck_tokens
         be, ve = self.bert_encoder, self.vit_encoder
         if vit is not None:
             E.rows_mix(tape, vit, text, I * nb, alpha=1.0, beta=0.0, d_idx=vit_bn_rows, s_idx=img_text_bn_rows)
-        spec_t = E.AttnSpec(nseq=M, S=St, H=be.heads, key_mask=text_mask_u8)
+        spec_t = E.AttnSpec(nseq=M, H=be.heads, **text_spec)
         text_out = E.transformer_block(tape, text, be.block_params(), spec_t, pre_ln=False, eps=be.eps, **be.drop_kwargs())
         vit_out = None
         if vit is not None:
@@ -89,7 +90,7 @@ class GraphFusionLayer(nn.Module):
             text = E.expand_sequences(tape, tv, M, Lq, nb, None)
             E.rows_mix(tape, text, bv, M * nb, alpha=1.0, beta=0.0, d_map=(nb, St, 0))
             vit = E.expand_sequences(tape, vv, I, P, nb, None) if vv is not None else None
-            t_out, v_out = self._fwd(tape, text, vit, M, St, I, Sv, mask, img_text_rows, vit_rows)
+            t_out, v_out = self._fwd(tape, text, vit, M, dict(S=St, key_mask=mask), I, Sv, img_text_rows, vit_rows)
             outs = [E.take_rows(tape, t_out, M * Lq, s_map=(Lq, St, nb)), E.take_rows(tape, t_out, M * nb, s_map=(nb, St, 0))]
             if v_out is not None:
                 outs.append(E.take_rows(tape, v_out, I * P, s_map=(P, Sv, nb)))

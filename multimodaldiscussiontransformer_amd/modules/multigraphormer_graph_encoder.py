@@ -15,13 +15,15 @@ structural attention bias is never materialised, graph tokens stay batch-major.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional, Tuple
 
 import torch
 import torch.nn as nn
 
 from .. import engine as E
-from ..data.packer import PackedBatch, packed_from_batched_data
+from ..data.packer import get_ragged, PackedBatch, packed_from_batched_data
 from ._fused import BertModel, ViTModel
 from .graphormer_graph_encoder_layer import GraphEncoderStack, GraphormerGraphEncoderLayer  # noqa: F401
 from .graphormer_layers import GraphAttnBias, GraphNodeFeature
@@ -115,6 +117,9 @@ class MultiGraphormerGraphEncoder(nn.Module):
             qn_block_size=qn_block_size, pre_layernorm=pre_layernorm) for _ in range(len(self.fusion_layers) + 1)])
         self.num_bottle_neck = num_bottle_neck
         self.bottle_neck = nn.Embedding(num_bottle_neck, embedding_dim)
+        # valid-token packing of the text side (see _indices); MDT_DENSE_TOKENS=1 or ``ragged_tokens = False`` runs
+        # the padded layout, which also reproduces the reference's hidden states at padded positions
+        self.ragged_tokens = os.environ.get("MDT_DENSE_TOKENS", "0") != "1"
 
         def set_grad(m, flag):
             if m is not None:
@@ -171,42 +176,72 @@ class MultiGraphormerGraphEncoder(nn.Module):
 
     # ------------------------------------------------------------------ index helpers
     def _indices(self, pb: PackedBatch):
+        """Row geometry of the text side, as index vectors, for the two layouts the tape can run in:
+        padded (every comment owns nb + L rows, attention masks the padding — bit-for-bit the reference, including
+        the hidden states of padded positions) and ragged (``ragged_tokens``, default: only valid tokens own rows;
+        logits and gradients are unchanged, see data/packer.py RaggedText)."""
         nb = self.num_bottle_neck
-        St = nb + pb.L
-        key = ("enc_idx", St)
+        ragged = bool(self.ragged_tokens)
+        key = ("enc_idx", nb, ragged)
         if key in pb.extras:
             return pb.extras[key]
         dev = pb.ids.device
+        M, Lq = pb.M, pb.L
         np_ = (self.vit_config["image_size"] // self.vit_config["patch"]) ** 2
         Sv = nb + np_ + 1
-        ones = torch.ones(pb.M, nb, dtype=torch.uint8, device=dev)
-        j = torch.arange(nb, device=dev, dtype=torch.int32)
+        i32 = dict(device=dev, dtype=torch.int32)
+        j = torch.arange(nb, **i32)
+        m_ar = torch.arange(M, **i32)
+        if ragged:
+            rt = get_ragged(pb)
+            off_pre = rt.offsets                                   # [M+1]
+            off_fus = (off_pre + torch.arange(M + 1, **i32) * nb).contiguous()
+            bn0 = off_fus[:M].contiguous()
+            pre2fus = (torch.arange(rt.rows, **i32) + (rt.comment + 1) * nb).contiguous()
+            rows_pre, rows_fus = rt.rows, rt.rows + M * nb
+            S_pre, S_fus = rt.max_len, rt.max_len + nb
+            spec_pre = dict(S=S_pre, seq_offsets=off_pre)
+            spec_fus = dict(S=S_fus, seq_offsets=off_fus)
+        else:
+            St = nb + Lq
+            bn0 = (m_ar * St).contiguous()
+            r = torch.arange(M * Lq, **i32)
+            pre2fus = (torch.div(r, Lq, rounding_mode="floor") * St + nb + r % Lq).contiguous()
+            rows_pre, rows_fus = M * Lq, M * St
+            ones = torch.ones(M, nb, dtype=torch.uint8, device=dev)
+            spec_pre = dict(S=Lq, key_mask=pb.text_mask)
+            spec_fus = dict(S=St, key_mask=torch.cat([ones, pb.text_mask], dim=1).contiguous())
         idx = dict(
-            St=St, Sv=Sv, P=np_ + 1,
-            fusion_mask=torch.cat([ones, pb.text_mask], dim=1).contiguous(),
-            text_row_of_node=torch.where(pb.node_row >= 0, pb.node_row * St, pb.node_row).contiguous(),
-            bn0_rows=(torch.arange(pb.M, device=dev, dtype=torch.int32) * St).contiguous(),
-            img_text_bn_rows=(pb.img_comment[:, None] * St + j[None]).reshape(-1).contiguous(),
-            vit_bn_rows=(torch.arange(pb.I, device=dev, dtype=torch.int32)[:, None] * Sv + j[None]).reshape(-1).contiguous(),
+            ragged=ragged, Sv=Sv, P=np_ + 1, rows_pre=rows_pre, rows_fus=rows_fus, spec_pre=spec_pre, spec_fus=spec_fus,
+            pre2fus=pre2fus, bn0_rows=bn0, cls_rows=(bn0 + nb).contiguous(),
+            bn_rows_all=(bn0[:, None] + j[None]).reshape(-1).contiguous(),
+            text_row_of_node=torch.where(pb.node_row >= 0, bn0[pb.node_row.clamp(min=0).long()], pb.node_row).contiguous(),
+            img_text_bn_rows=(bn0[pb.img_comment.long()][:, None] + j[None]).reshape(-1).contiguous(),
+            vit_bn_rows=(torch.arange(pb.I, **i32)[:, None] * Sv + j[None]).reshape(-1).contiguous(),
         )
         pb.extras[key] = idx
         return idx
 
     # ------------------------------------------------------------------ tape-level forward
     def _fwd(self, tape, pb: PackedBatch):
-        """→ (text buffer Var [M*(nb+L), D], global embedding Var [B, D])."""
+        """→ (text buffer Var [rows_fus, D] in the layout of ``_indices``, global embedding Var [B, D])."""
         tr = self.training
         p_emb = self.activation_dropout_p if tr else 0.0     # HF hidden_dropout_prob := act_dropout (:238,:243)
         nb = self.num_bottle_neck
         ix = self._indices(pb)
-        St, Sv, P = ix["St"], ix["Sv"], ix["P"]
-        M, Lq, I, B, T = pb.M, pb.L, pb.I, pb.B, pb.T
+        Sv, P = ix["Sv"], ix["P"]
+        M, I, B, T = pb.M, pb.I, pb.B, pb.T
         tm, vm = self.text_model, self.vit_model
         e = tm.embeddings
-        emb = E.bert_embeddings(tape, pb.ids, pb.types, e.word_embeddings.weight, e.position_embeddings.weight,
-                                e.token_type_embeddings.weight)
+        if ix["ragged"]:
+            rt = get_ragged(pb)
+            emb = E.bert_embeddings_rows(tape, rt.ids, rt.types, rt.pos, e.word_embeddings.weight,
+                                         e.position_embeddings.weight, e.token_type_embeddings.weight)
+        else:
+            emb = E.bert_embeddings(tape, pb.ids, pb.types, e.word_embeddings.weight, e.position_embeddings.weight,
+                                    e.token_type_embeddings.weight)
         text = E.dropout(tape, E.layernorm(tape, emb, e.LayerNorm.weight, e.LayerNorm.bias, tm.eps), p_emb)
-        spec0 = E.AttnSpec(nseq=M, S=Lq, H=tm.heads, key_mask=pb.text_mask)
+        spec0 = E.AttnSpec(nseq=M, H=tm.heads, **ix["spec_pre"])
         for layer in tm.encoder.layer:
             text = E.transformer_block(tape, text, layer.block_params(), spec0, pre_ln=False, eps=tm.eps,
                                        **layer.drop_kwargs())
@@ -222,8 +257,8 @@ class MultiGraphormerGraphEncoder(nn.Module):
                                         **layer.drop_kwargs())
             v = E.layernorm(tape, v, vm.layernorm.weight, vm.layernorm.bias, vm.eps)      # quirk 5: final LN mid-network
             vit = E.expand_sequences(tape, v, I, P, nb, None)
-        text = E.expand_sequences(tape, text, M, Lq, nb, self.bottle_neck.weight)
-        fargs = (M, St, I, Sv, ix["fusion_mask"], ix["img_text_bn_rows"], ix["vit_bn_rows"])
+        text = E.expand_rows(tape, text, ix["rows_fus"], ix["pre2fus"], ix["bn_rows_all"], nb, self.bottle_neck.weight)
+        fargs = (M, ix["spec_fus"], I, Sv, ix["img_text_bn_rows"], ix["vit_bn_rows"])
         text, vit = self.fusion_layers[0]._fwd(tape, text, vit, *fargs)
         gnf = self.graph_node_feature
         x = E.graph_node_features(tape, text, ix["text_row_of_node"], pb.degree, pb.degree, gnf.in_degree_encoder.weight,
@@ -241,10 +276,10 @@ class MultiGraphormerGraphEncoder(nn.Module):
         for st in range(F - 1):                       # zip(self.layers, self.fusion_layers[1:])  (:413)
             x = self.layers[st]._fwd(tape, x, gspec)
             # bottle_neck[:, 0, :] = x[mask]  (:425)
-            E.rows_mix(tape, text, x, M, alpha=1.0, beta=0.0, d_map=(1, St, 0), s_idx=pb.graph_row)
+            E.rows_mix(tape, text, x, M, alpha=1.0, beta=0.0, d_idx=ix["bn0_rows"], s_idx=pb.graph_row)
             text, vit = self.fusion_layers[st + 1]._fwd(tape, text, vit, *fargs)
             # x[mask] = bottle_neck[:, 0, :]  (:435)
-            E.rows_mix(tape, x, text, M, alpha=1.0, beta=0.0, d_idx=pb.graph_row, s_map=(1, St, 0))
+            E.rows_mix(tape, x, text, M, alpha=1.0, beta=0.0, d_idx=pb.graph_row, s_idx=ix["bn0_rows"])
         x = self.layers[-1]._fwd(tape, x, gspec)       # layers[F]; layers[F-1] is never executed (quirk 3)
         glob = E.take_rows(tape, x, B, s_map=(1, T, 0))
         return text, glob
@@ -269,7 +304,25 @@ class MultiGraphormerGraphEncoder(nn.Module):
             text, glob = self._fwd(tape, pb)
             return text, glob
 
-        buf, glob = E.run_tape(run, [], self.live_parameters(), use_main_grad=self.use_main_grad, hook=self.grad_ready_hook)
-        D = buf.shape[1]
-        buf = buf.view(pb.M, nb + pb.L, D)
-        return buf[:, nb:], buf[:, :nb], glob
+        ix = self._indices(pb)
+        if not ix["ragged"]:
+            buf, glob = E.run_tape(run, [], self.live_parameters(), use_main_grad=self.use_main_grad, hook=self.grad_ready_hook)
+            D = buf.shape[1]
+            buf = buf.view(pb.M, nb + pb.L, D)
+            return buf[:, nb:], buf[:, :nb], glob
+
+        # ragged tape: give the caller the reference's padded shapes; rows of padded positions (which the
+        # reference fills with the hidden states of padding tokens, never read by mDT) are zero
+        def run_padded(tape):
+            text, glob = self._fwd(tape, pb)
+            rt = get_ragged(pb)
+            dense_rows = (rt.comment * pb.L + rt.pos).contiguous()
+            fus_rows = ix["pre2fus"]
+            txt = E.scatter_rows(tape, text, pb.M * pb.L, dense_rows, fus_rows)
+            bn = E.take_rows(tape, text, pb.M * nb, s_idx=ix["bn_rows_all"])
+            return txt, bn, glob
+
+        txt, bn, glob = E.run_tape(run_padded, [], self.live_parameters(), use_main_grad=self.use_main_grad,
+                                   hook=self.grad_ready_hook)
+        D = txt.shape[1]
+        return txt.view(pb.M, pb.L, D), bn.view(pb.M, nb, D), glob

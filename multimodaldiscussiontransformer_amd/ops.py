@@ -15,6 +15,7 @@ from ._lib import (EPI_ACCUM, EPI_ATOMIC, EPI_AUX_GRAD, EPI_BIAS, EPI_COLSUM, EP
                    ptr, stream)
 
 __all__ = [
+    "bert_embed_rows",
     "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "graph_attn_bias",
     "row_axpby", "row_scatter_add", "bert_embed_sum", "vit_patchify", "vit_assemble", "graph_node_feature",
     "tanh_fwd", "tanh_bwd", "node_ce", "cast", "transpose2d", "dropout", "dropout_mask",
@@ -99,9 +100,12 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, add=None, dgamma=None, dbeta=None, d
 
 
 def _attn_args(qkv, out, lse, nseq, S, H, hd, seq_stride, pos_stride, scale, key_mask, dense_bias, attn_bias,
-               spatial_pos, sp_table, virt, key_pad, drop_p=0.0, drop_seed=0):
+               spatial_pos, sp_table, virt, key_pad, drop_p=0.0, drop_seed=0, seq_offsets=None):
     a = L.AttnFwdArgs()
     a.drop_p, a.drop_seed = float(drop_p), int(drop_seed)
+    assert seq_offsets is None or (seq_offsets.dtype == torch.int32 and seq_offsets.is_contiguous() and
+                                   seq_offsets.numel() == nseq + 1), "attention: seq_offsets must be i32[nseq + 1]"
+    a.seq_offsets = ptr(seq_offsets)
     a.dtype = dt(qkv)
     a.nseq, a.S, a.H, a.hd = nseq, S, H, hd
     a.seq_stride, a.pos_stride, a.scale = seq_stride, pos_stride, float(scale)
@@ -123,29 +127,31 @@ def _attn_args(qkv, out, lse, nseq, S, H, hd, seq_stride, pos_stride, scale, key
 
 
 def attention_fwd(qkv, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None, key_mask=None, dense_bias=None,
-                  attn_bias=None, spatial_pos=None, sp_table=None, virt=None, key_pad=None, drop_p=0.0, drop_seed=0):
-    """qkv [rows, 3*D] → (out [rows, D], lse f32[nseq, H, S])."""
+                  attn_bias=None, spatial_pos=None, sp_table=None, virt=None, key_pad=None, drop_p=0.0, drop_seed=0,
+                  seq_offsets=None):
+    """qkv [rows, 3*D] → (out [rows, D], lse f32[nseq, H, S]).  ``seq_offsets`` i32[nseq+1]: ragged sequences
+    (sequence s = rows off[s]..off[s+1], at most S of them), see include/mdt_hip.h."""
     D = qkv.shape[1] // 3
     hd = D // H
     out = torch.empty(qkv.shape[0], D, dtype=qkv.dtype, device=qkv.device)   # every row belongs to a sequence
     lse = torch.empty(nseq, H, S, dtype=torch.float32, device=qkv.device)
     a = _attn_args(qkv, out, lse, nseq, S, H, hd, S if seq_stride is None else seq_stride, pos_stride,
                    hd ** -0.5 if scale is None else scale, key_mask, dense_bias, attn_bias, spatial_pos, sp_table,
-                   virt, key_pad, drop_p, drop_seed)
+                   virt, key_pad, drop_p, drop_seed, seq_offsets)
     check(lib.mdt_attention_fwd(stream(), C.byref(a)), "mdt_attention_fwd")
     return out, lse
 
 
 def attention_bwd(dout, qkv, out, lse, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None, key_mask=None,
                   dense_bias=None, attn_bias=None, spatial_pos=None, sp_table=None, virt=None, key_pad=None,
-                  want_dense_dbias=False, d_sp_table=None, d_virt=None, drop_p=0.0, drop_seed=0):
+                  want_dense_dbias=False, d_sp_table=None, d_virt=None, drop_p=0.0, drop_seed=0, seq_offsets=None):
     D = qkv.shape[1] // 3
     hd = D // H
     dqkv = torch.empty_like(qkv)
     b = L.AttnBwdArgs()
     b.f = _attn_args(qkv, out, lse, nseq, S, H, hd, S if seq_stride is None else seq_stride, pos_stride,
                      hd ** -0.5 if scale is None else scale, key_mask, dense_bias, attn_bias, spatial_pos, sp_table,
-                     virt, key_pad, drop_p, drop_seed)
+                     virt, key_pad, drop_p, drop_seed, seq_offsets)
     b.dout, b.ld_dout = ptr(dout), _2d(dout)
     b.dqkv, b.ld_dqkv = ptr(dqkv), _2d(dqkv)
     dbias = None
@@ -192,6 +198,15 @@ def bert_embed_sum(ids, types, word, pos, type_emb, out, *, out_seq_stride, out_
     assert ids.dtype == torch.int32 and types.dtype == torch.int32 and ids.is_contiguous() and types.is_contiguous()
     check(lib.mdt_bert_embed_sum(stream(), dt(word), M, Lq, ptr(ids), ptr(types), ptr(word), ptr(pos), ptr(type_emb),
                                  word.shape[1], ptr(out), _2d(out), out_seq_stride, out_off), "mdt_bert_embed_sum")
+    return out
+
+
+def bert_embed_rows(ids, types, pos_ids, word, pos, type_emb, out):
+    rows = ids.numel()
+    for t in (ids, types, pos_ids):
+        assert t.dtype == torch.int32 and t.is_contiguous() and t.numel() == rows
+    check(lib.mdt_bert_embed_rows(stream(), dt(word), rows, ptr(ids), ptr(types), ptr(pos_ids), ptr(word), ptr(pos),
+                                  ptr(type_emb), word.shape[1], ptr(out), _2d(out)), "mdt_bert_embed_rows")
     return out
 
 

@@ -435,3 +435,42 @@ def test_node_ce_matches_oracle(ops):
     assert c.cpu().tolist() == [counters["ncorrect"], counters["num_positive_correct"], counters["total_positive"],
                                 counters["num_pred_positive"]]
     torch.testing.assert_close(dl.cpu(), lr.grad, atol=1e-3, rtol=1e-3)
+
+
+# ----------------------------------------------------------------------------- ragged attention
+@pytest.mark.parametrize("dtype,bwd", [(torch.float32, None), (torch.bfloat16, None), (torch.bfloat16, "v1"), (torch.bfloat16, "v2")])
+@pytest.mark.parametrize("Smax,H", [(40, 2), (104, 3), (201, 2)])
+def test_attention_ragged_sequences_equal_masked_padding(ops, dtype, bwd, Smax, H, monkeypatch):
+    """seq_offsets (valid tokens packed back to back) against the same sequences padded to Smax behind a key mask:
+    outputs and gradients at the valid rows agree, for every kernel family, with attention dropout on (the counters
+    keep the padded geometry, so the two runs draw the same masks)."""
+    if bwd == "v2" and Smax > 112:
+        pytest.skip("whole-row backward covers S <= 112")
+    if bwd:
+        monkeypatch.setenv("MDT_ATTN_BWD", bwd)
+    hd, p, seed = 64, 0.25, 31
+    D = H * hd
+    lens = [Smax, 1, 17, Smax - 3, 5, 33 if Smax > 33 else 2]
+    nseq = len(lens)
+    off = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    rows = int(off[-1])
+    qkv_r = rnd(rows, 3 * D, seed=3).to(dtype)
+    dout_r = rnd(rows, D, seed=4).to(dtype)
+    qkv_p = torch.zeros(nseq, Smax, 3 * D, dtype=dtype)
+    dout_p = torch.zeros(nseq, Smax, D, dtype=dtype)
+    km = torch.zeros(nseq, Smax, dtype=torch.uint8)
+    for s_, n in enumerate(lens):
+        qkv_p[s_, :n] = qkv_r[off[s_]:off[s_] + n]
+        dout_p[s_, :n] = dout_r[off[s_]:off[s_] + n]
+        km[s_, :n] = 1
+    out_p, lse_p = ops.attention_fwd(dev(qkv_p.view(-1, 3 * D)), nseq, Smax, H, key_mask=dev(km), drop_p=p, drop_seed=seed)
+    dq_p, _ = ops.attention_bwd(dev(dout_p.view(-1, D)), dev(qkv_p.view(-1, 3 * D)), out_p, lse_p, nseq, Smax, H,
+                                key_mask=dev(km), drop_p=p, drop_seed=seed)
+    out_r, lse_r = ops.attention_fwd(dev(qkv_r), nseq, Smax, H, seq_offsets=dev(off), drop_p=p, drop_seed=seed)
+    dq_r, _ = ops.attention_bwd(dev(dout_r), dev(qkv_r), out_r, lse_r, nseq, Smax, H, seq_offsets=dev(off), drop_p=p, drop_seed=seed)
+    tol = dict(atol=1e-5, rtol=1e-5) if dtype == torch.float32 else dict(atol=2e-2, rtol=2e-2)
+    out_p, dq_p = out_p.view(nseq, Smax, D).float().cpu(), dq_p.view(nseq, Smax, 3 * D).float().cpu()
+    for s_, n in enumerate(lens):
+        torch.testing.assert_close(out_r[off[s_]:off[s_] + n].float().cpu(), out_p[s_, :n], **tol)
+        torch.testing.assert_close(dq_r[off[s_]:off[s_] + n].float().cpu(), dq_p[s_, :n], **tol)
+        torch.testing.assert_close(lse_r[s_, :, :n].cpu(), lse_p[s_, :, :n].cpu(), atol=1e-4, rtol=1e-5)

@@ -154,7 +154,7 @@ def test_fusion_layer_vs_reference_golden(golden_dir):
 
 
 # ------------------------------------------------------------------------------- full model
-def _run_full(kind, dtype, use_main_grad=False):
+def _run_full(kind, dtype, use_main_grad=False, ragged=True):
     from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
     from multimodaldiscussiontransformer_amd.data.packer import pack_batch
     from multimodaldiscussiontransformer_amd.models import GraphormerModel
@@ -164,6 +164,7 @@ def _run_full(kind, dtype, use_main_grad=False):
     fill_hash_weights(model)
     model = model.cuda().to(dtype)
     model.train()
+    model.encoder.graph_encoder.ragged_tokens = ragged      # valid-token packing vs the reference's padded layout
     if use_main_grad:
         model.prepare_main_grads()
     pb = pack_batch(trees, 5)
@@ -174,10 +175,14 @@ def _run_full(kind, dtype, use_main_grad=False):
     return hp, trees, model, pb, loss, sample_size, log
 
 
+@pytest.mark.parametrize("ragged", [False, True])
 @pytest.mark.parametrize("kind", ["A", "B"])
-def test_full_model_fp32_vs_reference_golden_and_oracle(golden_dir, kind):
+def test_full_model_fp32_vs_reference_golden_and_oracle(golden_dir, kind, ragged):
+    """Both text layouts against the reference's golden vectors: the padded one reproduces everything, the ragged one
+    (padded token positions never computed) everything except the hidden states AT padded positions, which it
+    returns as zeros — logits, loss, counters and every parameter gradient are held to the same 1e-3 gate."""
     g = _g(golden_dir, f"full_tiny768_{kind}.npz")
-    hp, trees, model, pb, loss, sample_size, log = _run_full(kind, torch.float32)
+    hp, trees, model, pb, loss, sample_size, log = _run_full(kind, torch.float32, ragged=ragged)
     # structural tensors handed to the kernels are the reference's, bit for bit
     ref_b = S.collate(trees, 5)
     for k in ("attn_bias", "spatial_pos", "in_degree", "x_token_mask", "x", "x_attention_mask", "x_image_indexes", "y_mask"):
@@ -187,7 +192,10 @@ def test_full_model_fp32_vs_reference_golden_and_oracle(golden_dir, kind):
         text, bn, glob2 = model.encoder.graph_encoder(pb.batched_data)
     np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], atol=1e-3)
     np.testing.assert_allclose(glob.cpu().numpy(), g["enc/global"], atol=1e-3)
-    np.testing.assert_allclose(text[:, :3, :64].cpu().numpy(), g["enc/text_slice"], atol=1e-3)
+    valid = pb.text_mask[:, :3].bool().cpu().numpy()[:, :, None] if ragged else np.ones((pb.M, 3, 1), dtype=bool)
+    np.testing.assert_allclose(text[:, :3, :64].cpu().numpy() * valid, g["enc/text_slice"] * valid, atol=1e-3)
+    if ragged:
+        assert float(text.cpu()[~pb.text_mask.bool().cpu()].abs().max() if (~pb.text_mask.bool()).any() else 0.0) == 0.0
     np.testing.assert_allclose(bn.cpu().numpy(), g["enc/bn"], atol=1e-3)
     assert abs(float(loss) - float(g["loss"])) <= 2e-2          # fp16 loss value: 1 ulp at ~8 is 7.8e-3
     assert sample_size == int(g["sample_size"])
@@ -232,6 +240,38 @@ def test_full_model_fp32_vs_reference_golden_and_oracle(golden_dir, kind):
         ref = W[name].grad
         tol = 1e-3 * max(1.0, float(ref.abs().max()))
         assert float((gr.float().cpu() - ref).abs().max()) <= tol, name
+
+
+def test_ragged_tokens_equal_padded_tokens_fp32():
+    """Same weights, same batch (random comment lengths, one mask with a hole): logits, loss and every parameter
+    gradient of the ragged layout equal the padded layout's to fp32 round-off."""
+    from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
+    from multimodaldiscussiontransformer_amd.data.packer import pack_batch
+    from multimodaldiscussiontransformer_amd.models import GraphormerModel
+    from multimodaldiscussiontransformer_amd import synthetic
+    hp = cases.tiny_hparams("A")
+    trees = synthetic.make_trees(3, 6, seed=77, seq_len=24, vocab_size=hp.vocab_size, image_frac=0.34, image_size=hp.image_size, min_len=2)
+    trees[0]["attention_mask"][1, 1] = 0                      # a hole: position 1 masked, later ones valid
+    res = {}
+    for ragged in (False, True):
+        model = GraphormerModel.build_model(model_args(hp), task=None)
+        fill_hash_weights(model)
+        model = model.cuda().eval()                           # eval: no dropout, so the two layouts are comparable
+        model.encoder.graph_encoder.ragged_tokens = ragged
+        pb = pack_batch(trees, 5)
+        crit = GraphPredictionNodeCrossEntropy(None, positive_weight=1.5, negative_weight=1.0)
+        loss, _, _ = crit(model, {"nsamples": len(trees), "net_input": {"batched_data": pb.batched_data}})
+        loss.backward()
+        with torch.no_grad():
+            logits, glob = model(pb.batched_data)
+        res[ragged] = (float(loss), logits.cpu(), glob.cpu(), {n: p.grad.cpu() for n, p in model.named_parameters() if p.grad is not None})
+    (l0, lg0, gl0, g0), (l1, lg1, gl1, g1) = res[False], res[True]
+    assert abs(l0 - l1) < 1e-5
+    torch.testing.assert_close(lg1, lg0, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(gl1, gl0, atol=2e-5, rtol=1e-5)
+    assert set(g0) == set(g1)
+    for n in g0:
+        torch.testing.assert_close(g1[n], g0[n], atol=2e-5 * max(1.0, float(g0[n].abs().max())), rtol=1e-4, msg=n)
 
 
 def test_full_model_main_grad_equals_autograd_grads():

@@ -5,7 +5,7 @@ import sys
 
 src = sys.argv[1]
 r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                    "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"], capture_output=True, text=True)
+                    "-Rpass-analysis=kernel-resource-usage"] + (["-mllvm", "-amdgpu-mfma-vgpr-form=1"] if "attention" in src else []) + ["-c", src, "-o", "/dev/null"], capture_output=True, text=True)
 blocks = re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]
 for b in blocks:
     name = b.split("\n")[0].strip().split()[0]
