@@ -51,11 +51,16 @@ def base_args(a):
         num_classes=1)
 
 
-def flops_per_comment(L=100, nb=4, P=197, D=768, F=3072, Lb=6, Lf=6, G=6, N=64, Fg=768, rho=0.25, patch=16):
-    """Algorithmic forward FLOPs per comment."""
+def flops_per_comment(L=100, nb=4, P=197, D=768, F=3072, Lb=6, Lf=6, G=6, N=64, Fg=768, rho=0.25, patch=16, lens=None):
+    """Algorithmic forward FLOPs per comment.  ``lens``: valid-token counts of the comments when the
+    text side runs ragged (the padded reference spends ``L`` tokens on every comment)."""
     def enc(S):
         return 8 * S * D * D + 4 * S * D * F + 4 * S * S * D
-    text = Lb * enc(L) + Lf * enc(L + nb)
+    if lens is None:
+        text = Lb * enc(L) + Lf * enc(L + nb)
+    else:
+        lens = [float(x) for x in lens]
+        text = sum(Lb * enc(x) + Lf * enc(x + nb) for x in lens) / len(lens)
     image = 2 * (P - 1) * (3 * patch * patch) * D + Lb * enc(P) + Lf * enc(P + nb)
     T = N + 1
     graph_tree = G * (8 * T * D * D + 4 * T * D * Fg + 4 * T * T * D)
@@ -307,8 +312,12 @@ def main():
     value = total_comments / dt
 
     if rank == 0:
-        fpc = flops_per_comment(Lb=12 - (args.num_fusion_layers + 1), Lf=args.num_fusion_layers + 1,
-                                G=args.num_fusion_layers + 1, N=args.nodes, rho=args.image_frac)
+        ragged = bool(model.encoder.graph_encoder.ragged_tokens)
+        tok_lens = batches[0].text_mask.sum(1).tolist()
+        fkw = dict(Lb=12 - (args.num_fusion_layers + 1), Lf=args.num_fusion_layers + 1, G=args.num_fusion_layers + 1,
+                   N=args.nodes, rho=args.image_frac)
+        fpc = flops_per_comment(lens=tok_lens if ragged else None, **fkw)      # FLOPs this implementation executes
+        fpc_padded = flops_per_comment(**fkw)                                  # FLOPs of the reference's padded layout
         gs = timer.summary()
         roofline = None
         traffic, traffic_src = None, None
@@ -333,11 +342,15 @@ def main():
             "config": {"workload": "mDT-base (BERT-base + ViT-B/16 split 6+6, 6 executed graph layers, D768 H12 nb4 L100), "
                                    f"{args.trees} bushy {args.nodes}-comment trees per GPU, {int(args.image_frac * 100)}% image comments, "
                                    f"random-init weights, dropout {args.dropout}/{args.attention_dropout}/{args.act_dropout} (run_train.sh:37), "
-                                   "no optimizer step",
+                                   f"token lengths U{{8..100}} zero-padded to 100 (SURVEY.md §8d; mean {sum(tok_lens) / len(tok_lens):.1f} valid tokens), "
+                                   + ("text side ragged: padded token positions are not computed (identical logits / gradients), "
+                                      if ragged else "text side padded to 100 tokens as in the reference, ") + "no optimizer step",
                        "trees_per_gpu": args.trees, "comments_per_step_per_gpu": comments_per_step,
                        "parallelism": f"dp{world}", "frozen_initial_encoders": bool(args.freeze_initial_encoders)},
             "model_tflops": round(value * 3 * fpc / 1e12, 1),
             "model_frac_of_bf16_peak": round(value * 3 * fpc / 1e12 / (BF16_DENSE_PEAK_TFLOPS * world), 4),
+            "padded_equivalent_tflops": round(value * 3 * fpc_padded / 1e12, 1),
+            "text_layout": "ragged" if ragged else "padded",
             "roofline": roofline,
             "selfcheck": "skipped" if (args.no_selfcheck or args.dtype != "bf16") else "passed",
         }
