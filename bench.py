@@ -301,6 +301,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    t_issue = time.perf_counter() - t0           # host time to ENQUEUE the steps (no sync inside a step)
     fence()
     dt = time.perf_counter() - t0
     timer.enabled = False
@@ -351,6 +352,7 @@ def main():
             "model_frac_of_bf16_peak": round(value * 3 * fpc / 1e12 / (BF16_DENSE_PEAK_TFLOPS * world), 4),
             "padded_equivalent_tflops": round(value * 3 * fpc_padded / 1e12, 1),
             "text_layout": "ragged" if ragged else "padded",
+            "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 2),
             "roofline": roofline,
             "selfcheck": "skipped" if (args.no_selfcheck or args.dtype != "bf16") else "passed",
         }

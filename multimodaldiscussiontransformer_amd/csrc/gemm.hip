@@ -917,6 +917,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
   };
   static_assert(PP_DIST >= 2 && PP_DIST <= 4, "wait_pieces assumes at most 3 steps left in flight");
 
+  if (p.epilogue & (1 << 22)) {   // diagnostic (MDT_GEMM_DIAG=4): skew the workgroups of an XCD so their epilogues do not coincide
+    const int steps = ((blockIdx.x >> 3) & 7) * (nhs / 8);
+    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(28);   // ~ one 32-k step each
+  }
   int v = blockIdx.x;
   Desc cur = make_desc(v);
   bool has_next = v + (int)gridDim.x < nvt;

@@ -1,6 +1,6 @@
 set -e
-out=gpurun_out/ab42.log; rm -f $out
-for cfg in "MDT_DENSE_TOKENS=0" "MDT_DENSE_TOKENS=1" "MDT_DENSE_TOKENS=0"; do
+out=gpurun_out/ab46.log; rm -f $out
+for cfg in "MDT_X=0" "MDT_GEMM_DIAG=4" "MDT_X=0" "MDT_GEMM_DIAG=4"; do
   echo "== $cfg" >> $out
-  env $cfg timeout -k 10 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | cut -c1-220 >> $out
+  env $cfg timeout -k 10 200 python tools/kbench.py --gemm-only 2>/dev/null | grep "fwd\|dgrad" >> $out
 done
