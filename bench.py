@@ -216,6 +216,37 @@ def selfcheck():
     torch.cuda.synchronize()
 
 
+def selfcheck_model(model, pb, build_fp32):
+    """End-to-end guard at the bench's own batch: bf16 logits of the tape that is about to be timed (ragged text,
+    big-tile persistent GEMMs, v2 / v3 attention) against (a) the same weights run in fp32 through the parity path
+    (generic fp32 MFMA GEMMs, fp32 attention — the path the golden-vector tests pin to the reference) and (b) the
+    bf16 tape in the reference's padded text layout.  Eval mode (no dropout), forward only."""
+    ge = model.encoder.graph_encoder
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        lg, glob = model(pb.batched_data)
+        keep = ge.ragged_tokens
+        ge.ragged_tokens = not keep
+        lg_other, glob_other = model(pb.batched_data)
+        ge.ragged_tokens = keep
+        m32 = build_fp32()
+        m32.load_state_dict(model.state_dict())          # same (bf16-rounded) weights, fp32 arithmetic
+        m32.eval()
+        lg32, glob32 = m32(pb.batched_data)
+        del m32
+    model.train(was_training)
+    d_layout = float((lg.float() - lg_other.float()).abs().max())
+    d_fp32 = float((lg.float() - lg32).abs().max())
+    scale = max(1.0, float(lg32.abs().max()))
+    if not (d_layout <= 0.05 * scale and d_fp32 <= 0.08 * scale):
+        raise SystemExit(f"bench self-check failed: bf16 logits differ from the padded layout by {d_layout:.3g} and from the "
+                         f"fp32 parity path by {d_fp32:.3g} (|logits| up to {scale:.3g})")
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    return dict(logits_vs_fp32_parity_path=round(d_fp32, 4), logits_ragged_vs_padded=round(d_layout, 4), logits_absmax=round(scale, 3))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -279,6 +310,10 @@ def main():
                                      image_frac=args.image_frac, image_size=224)
         batches.append(pack_batch(trees, spatial_pos_max=5))
     torch.cuda.synchronize()
+    model_check = None
+    if args.dtype == "bf16" and not args.no_selfcheck:
+        model_check = selfcheck_model(model, batches[0],
+                                      lambda: GraphormerModel.build_model(base_args(args), task=None).cuda().float())
     comments_per_step = batches[0].M
     scal = torch.zeros(6, dtype=torch.float32, device="cuda")
 
@@ -363,7 +398,7 @@ def main():
             "text_layout": "ragged" if ragged else "padded",
             "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 2),
             "roofline": roofline,
-            "selfcheck": "skipped" if (args.no_selfcheck or args.dtype != "bf16") else "passed",
+            "selfcheck": "skipped" if (args.no_selfcheck or args.dtype != "bf16") else dict(kernels="passed", **(model_check or {})),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
