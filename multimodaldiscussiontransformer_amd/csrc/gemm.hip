@@ -380,13 +380,14 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
 // columns per lane (odd 16-lane rows of tile j trade places with even rows of tile j + 1), so bias, saved
 // pre-activation, residual and output all move as 16-byte vectors covering 64 contiguous bytes of 16 rows
 // per wave instruction — no LDS parking, no workgroup barrier, and no wave waits for another one.
-__device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc)[8][4], int lane, int64_t m0w, int64_t n0w) {
+template <int NJP>   // NJP pairs of 16-column tiles per wave: 2 (128x64 blocks) or 4 (128x128 blocks)
+__device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc)[8][2 * NJP], int lane, int64_t m0w, int64_t n0w) {
   const int c = lane & 15, g = lane >> 4;
   const int ep = p.epilogue;
-  int64_t gcs[2];
-  float bias[2][8];
+  int64_t gcs[NJP];
+  float bias[NJP][8];
 #pragma unroll
-  for (int jp = 0; jp < 2; ++jp) {
+  for (int jp = 0; jp < NJP; ++jp) {
     gcs[jp] = n0w + 32 * jp + 16 * (g & 1) + 8 * (g >> 1);
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[jp][e] = 0.f;
@@ -396,9 +397,9 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
       for (int e = 0; e < 8; ++e) bias[jp][e] = (float)b[e];
     }
   }
-  float cs[2][8];
+  float cs[NJP][8];
 #pragma unroll
-  for (int jp = 0; jp < 2; ++jp)
+  for (int jp = 0; jp < NJP; ++jp)
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[jp][e] = 0.f;
   // The eight row groups are expanded by hand (generic lambda over a compile-time index): hipcc does not unroll a
@@ -408,7 +409,7 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
     const int64_t gr = m0w + 16 * i + c;
     const bool live = gr < p.M;
 #pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
+    for (int jp = 0; jp < NJP; ++jp) {
       float v[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -507,7 +508,7 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
   row_group(std::integral_constant<int, 6>{}); row_group(std::integral_constant<int, 7>{});
   if (ep & MDT_EPI_COLSUM) {   // the 16 lanes of a row group hold 16 rows of the same columns
 #pragma unroll
-    for (int jp = 0; jp < 2; ++jp)
+    for (int jp = 0; jp < NJP; ++jp)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float s_ = row16_sum(cs[jp][e]);
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
     o[3] = t_real;
   }
   if constexpr (SWAP) {
-    direct_epilogue(p, acc, lane, m0 + wr * 128, n0 + wc * 64);
+    direct_epilogue<2>(p, acc, lane, m0 + wr * 128, n0 + wc * 64);
     return;
   }
 #pragma unroll
@@ -976,7 +977,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
     }
     if (!late) __builtin_amdgcn_s_barrier();     // both groups leave the tile together
     if (p.stamps) { s_cyc += __builtin_amdgcn_s_memtime() - t_cyc; s_real += __builtin_amdgcn_s_memrealtime() - t_real; s_nk += nhs / 2; }
-    direct_epilogue(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 64);
+    direct_epilogue<2>(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 64);
     if (!has_next) break;
     v += gridDim.x;
     cur = nxt;

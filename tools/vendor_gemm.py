@@ -1,0 +1,24 @@
+"""Context only: torch.matmul (hipBLASLt / rocBLAS) on the bench's GEMM shapes, same box, same random data."""
+import sys
+import torch
+sys.path.insert(0, ".")
+from tools.kbench import timeit
+from multimodaldiscussiontransformer_amd import ops
+
+bf = torch.bfloat16
+for M in (212992, 118784):
+    for (n, k, name) in [(2304, 768, "qkv fwd"), (768, 768, "out fwd"), (3072, 768, "ffn1 fwd"), (768, 3072, "ffn2 fwd")]:
+        a = torch.randn(M, k, device="cuda", dtype=bf)
+        w = torch.randn(n, k, device="cuda", dtype=bf)
+        out = torch.empty(M, n, device="cuda", dtype=bf)
+        t_v = timeit(lambda: torch.matmul(a, w.t(), out=out))
+        t_o = timeit(lambda: ops.gemm(a, w, out=out))
+        fl = 2 * M * n * k
+        print(f"M={M} {name:9s}: vendor {fl/t_v/1e12:7.1f} TF/s   ours {fl/t_o/1e12:7.1f} TF/s", flush=True)
+    # wgrad shape
+    dy = torch.randn(M, 3072, device="cuda", dtype=bf); x = torch.randn(M, 768, device="cuda", dtype=bf)
+    c = torch.zeros(3072, 768, device="cuda", dtype=torch.float32)
+    t_v = timeit(lambda: torch.matmul(dy.t(), x))
+    t_o = timeit(lambda: ops.gemm(dy, x, trans_a=True, trans_b=True, out=c, epilogue=ops.EPI_ATOMIC, split_k=7))
+    fl = 2 * M * 3072 * 768
+    print(f"M={M} ffn1 wgrad: vendor {fl/t_v/1e12:7.1f} TF/s (bf16 out)   ours {fl/t_o/1e12:7.1f} TF/s (fp32 accumulate into the arena)", flush=True)
