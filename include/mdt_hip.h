@@ -236,6 +236,20 @@ int mdt_adam_step(void* stream, int dtype, int64_t n, void* param, float* master
                   float* v, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   const float* grad_scale);
 
+/* Multi-tensor form: ONE launch over a device-resident table of same-dtype parameter tensors.  chunk_first[t] = first
+ * 4096-element chunk of tensor t, chunk_first[n_tensors] = total_chunks (int64, device). */
+typedef struct {
+  void* param;          /* T[numel] */
+  float* master;        /* fp32 copy or NULL */
+  const float* grad;    /* fp32 */
+  float* m;
+  float* v;
+  int64_t numel;
+} mdt_adam_tensor;
+int mdt_adam_step_multi(void* stream, int dtype, int n_tensors, const mdt_adam_tensor* table_dev,
+                        const int64_t* chunk_first_dev, int64_t total_chunks, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int step, const float* grad_scale);
+
 /* ------------------------------------------------------------------ packer (host, C++)
  * Native replacement of preprocess_item + collator (data/pyg_datasets/pre_processing.py:18-69,
  * data/collator.py:69-179): integer tensors are bit-exact with the reference.

@@ -34,6 +34,33 @@ def test_fused_adam_matches_reference_formula():
     assert abs(s(7033) - ((3e-5 - 3e-7) * 0.5 + 3e-7)) < 1e-9
 
 
+def test_fused_adam_multi_tensor_matches_per_tensor():
+    """One-launch table walk (several tensors, sizes around the 4096-element chunk, bf16 with fp32 masters, gradient
+    views that move as after the DDP arena re-layout) against the per-tensor kernel."""
+    from multimodaldiscussiontransformer_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(1)
+    shapes = [(5,), (4096,), (4097,), (300, 41), (70000,)]
+    for dtype in (torch.float32, torch.bfloat16):
+        init = [torch.randn(s, generator=g) for s in shapes]
+        pa = [torch.nn.Parameter(t.clone().cuda().to(dtype)) for t in init]     # multi-tensor path (main_grad arena)
+        pb = [torch.nn.Parameter(t.clone().cuda().to(dtype)) for t in init]     # per-tensor path (p.grad)
+        arena = torch.zeros(sum(t.numel() for t in init) + 64, device="cuda")
+        oa, ob = FusedAdam(pa, lr=1e-2), FusedAdam(pb, lr=1e-2, multi_tensor=False)
+        for step in range(3):
+            off = 64 if step == 2 else 0                                        # step 2: every view moved
+            o = off
+            for p_, q_ in zip(pa, pb):
+                gr = torch.randn(p_.shape, generator=g).cuda()
+                p_.main_grad = arena[o:o + p_.numel()].view(p_.shape)
+                p_.main_grad.copy_(gr)
+                q_.main_grad = gr.clone()
+                o += p_.numel()
+            oa.step()
+            ob.step()
+        for p_, q_ in zip(pa, pb):
+            assert torch.equal(p_.detach(), q_.detach())
+
+
 def test_launcher_trains_and_loss_decreases(tmp_path):
     from multimodaldiscussiontransformer_amd import train
     ck = tmp_path / "ck.pt"
