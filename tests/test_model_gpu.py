@@ -274,6 +274,51 @@ def test_ragged_tokens_equal_padded_tokens_fp32():
         torch.testing.assert_close(g1[n], g0[n], atol=2e-5 * max(1.0, float(g0[n].abs().max())), rtol=1e-4, msg=n)
 
 
+def test_tree_permutation_and_node_padding_invariance_fp32():
+    """SURVEY.md §4 property tests: (a) permuting the trees of a batch permutes the per-comment logits and leaves
+    the loss and every parameter gradient unchanged; (b) adding a larger tree to the batch (more node padding N,
+    other trees untouched) does not change the logits of the original comments."""
+    from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
+    from multimodaldiscussiontransformer_amd.data.packer import pack_batch
+    from multimodaldiscussiontransformer_amd.models import GraphormerModel
+    from multimodaldiscussiontransformer_amd import synthetic
+    hp = cases.tiny_hparams("A")
+    trees = synthetic.make_trees(3, 7, seed=91, variable=True, seq_len=16, vocab_size=hp.vocab_size, image_frac=0.3,
+                                 image_size=hp.image_size, min_len=3)
+    big = synthetic.make_trees(1, 13, seed=92, seq_len=16, vocab_size=hp.vocab_size, image_frac=0.3,
+                               image_size=hp.image_size, min_len=3)
+    model = GraphormerModel.build_model(model_args(hp), task=None)
+    fill_hash_weights(model)
+    model = model.cuda().eval()
+    crit = GraphPredictionNodeCrossEntropy(None, positive_weight=1.5, negative_weight=1.0)
+
+    def run(ts, grads=True):
+        model.zero_grad(set_to_none=True)
+        pb = pack_batch(ts, 5)
+        if grads:
+            loss, _, _ = crit(model, {"nsamples": len(ts), "net_input": {"batched_data": pb.batched_data}})
+            loss.backward()
+        with torch.no_grad():
+            logits, glob = model(pb.batched_data)
+        g = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None} if grads else {}
+        return (float(loss) if grads else None), logits.cpu(), glob.cpu(), g
+
+    l0, lg0, gl0, g0 = run(trees)
+    perm = [2, 0, 1]
+    l1, lg1, gl1, g1 = run([trees[i] for i in perm])
+    sizes = [len(t["parent"]) for t in trees]
+    starts = np.cumsum([0] + sizes)
+    want = torch.cat([lg0[starts[i]:starts[i + 1]] for i in perm])
+    torch.testing.assert_close(lg1, want, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(gl1, gl0[perm], atol=2e-5, rtol=1e-5)
+    assert abs(l0 - l1) < 1e-5
+    for n in g0:
+        torch.testing.assert_close(g1[n], g0[n], atol=2e-5 * max(1.0, float(g0[n].abs().max())), rtol=1e-4, msg=n)
+    _, lg2, gl2, _ = run(trees + big, grads=False)
+    torch.testing.assert_close(lg2[: starts[-1]], lg0, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(gl2[:3], gl0, atol=2e-5, rtol=1e-5)
+
+
 def test_full_model_main_grad_equals_autograd_grads():
     _, _, m1, _, _, _, _ = _run_full("A", torch.float32, use_main_grad=False)
     _, _, m2, _, _, _, _ = _run_full("A", torch.float32, use_main_grad=True)
