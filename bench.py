@@ -51,17 +51,24 @@ def base_args(a):
         num_classes=1)
 
 
-def flops_per_comment(L=100, nb=4, P=197, D=768, F=3072, Lb=6, Lf=6, G=6, N=64, Fg=768, rho=0.25, patch=16, lens=None):
+def flops_per_comment(L=100, nb=4, P=197, D=768, F=3072, Lb=6, Lf=6, G=6, N=64, Fg=768, rho=0.25, patch=16, lens=None,
+                      prune_last=False):
     """Algorithmic forward FLOPs per comment.  ``lens``: valid-token counts of the comments when the
-    text side runs ragged (the padded reference spends ``L`` tokens on every comment)."""
-    def enc(S):
-        return 8 * S * D * D + 4 * S * D * F + 4 * S * S * D
+    text side runs ragged (the padded reference spends ``L`` tokens on every comment).  ``prune_last``: the last
+    fusion layer runs its output projection and FFN only on the rows that are read afterwards (2 per comment, 1 per
+    image) — the reference computes (and discards) all of them."""
+    def enc(S, kept=None):
+        rows = S if kept is None else kept
+        return 6 * S * D * D + 4 * S * S * D + rows * (2 * D * D + 4 * D * F)
+
+    def stack(S, kept):
+        return (Lf - 1) * enc(S + nb) + enc(S + nb, kept if prune_last else None)
     if lens is None:
-        text = Lb * enc(L) + Lf * enc(L + nb)
+        text = Lb * enc(L) + stack(L, 2)
     else:
         lens = [float(x) for x in lens]
-        text = sum(Lb * enc(x) + Lf * enc(x + nb) for x in lens) / len(lens)
-    image = 2 * (P - 1) * (3 * patch * patch) * D + Lb * enc(P) + Lf * enc(P + nb)
+        text = sum(Lb * enc(x) + stack(x, 2) for x in lens) / len(lens)
+    image = 2 * (P - 1) * (3 * patch * patch) * D + Lb * enc(P) + stack(P, 1)
     T = N + 1
     graph_tree = G * (8 * T * D * D + 4 * T * D * Fg + 4 * T * T * D)
     head = 2 * (2 * D * D + 4 * D)
@@ -360,7 +367,8 @@ def main():
         tok_lens = batches[0].text_mask.sum(1).tolist()
         fkw = dict(Lb=12 - (args.num_fusion_layers + 1), Lf=args.num_fusion_layers + 1, G=args.num_fusion_layers + 1,
                    N=args.nodes, rho=args.image_frac)
-        fpc = flops_per_comment(lens=tok_lens if ragged else None, **fkw)      # FLOPs this implementation executes
+        pruned = bool(model.encoder.graph_encoder.prune_last_layer)
+        fpc = flops_per_comment(lens=tok_lens if ragged else None, prune_last=pruned, **fkw)   # FLOPs this implementation executes
         fpc_padded = flops_per_comment(**fkw)                                  # FLOPs of the reference's padded layout
         gs = timer.summary()
         roofline = None
@@ -389,6 +397,7 @@ def main():
                                    f"token lengths U{{8..100}} zero-padded to 100 (SURVEY.md §8d; mean {sum(tok_lens) / len(tok_lens):.1f} valid tokens), "
                                    + ("text side ragged: padded token positions are not computed (identical logits / gradients), "
                                       if ragged else "text side padded to 100 tokens as in the reference, ")
+                                   + ("last fusion layer computes only the rows read afterwards, " if pruned else "")
                                    + ("fused Adam step included" if opt is not None else "no optimizer step (metric: fwd+bwd)"),
                        "trees_per_gpu": args.trees, "comments_per_step_per_gpu": comments_per_step,
                        "parallelism": f"dp{world}", "frozen_initial_encoders": bool(args.freeze_initial_encoders)},

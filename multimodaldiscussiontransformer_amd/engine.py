@@ -178,7 +178,7 @@ def _ln_bwd_dense(tape, dy, x, w, b, mean, rstd, bias_param, p_drop, seed, add=N
 # ------------------------------------------------------------------------------------------
 # ops
 def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre_ln: bool, eps: float,
-                      p_hidden: float = 0.0, p_attn: float = 0.0, p_act: float = 0.0) -> Var:
+                      p_hidden: float = 0.0, p_attn: float = 0.0, p_act: float = 0.0, keep_rows=None) -> Var:
     """One encoder block (post-LN: HF BertLayer / Graphormer layer; pre-LN: HF ViTLayer or
     Graphormer with --pre-layernorm).  7 GEMM-class launches + attention + 2 LayerNorms
     forward; the adjoint below mirrors it with the residual adds folded into epilogues.
@@ -186,15 +186,40 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
     ``p_hidden`` on the two dense outputs before their residual adds and ``p_act`` after GELU
     (both in the GEMM epilogue); masks are regenerated in backward from per-site seeds.  The FFN
     saves ``u`` = d h / d pre-activation (GELU' times the activation-dropout scale) rather than
-    the pre-activation itself, so the backward epilogue is a single multiply."""
+    the pre-activation itself, so the backward epilogue is a single multiply.
+
+    ``keep_rows`` (i32[R]): only these token rows of the block's OUTPUT are needed downstream (the last fusion
+    layer feeds nothing but bottleneck token 0 and [CLS] of every comment to the graph / the head).  Keys and
+    values still come from every row, but the output projection, both LayerNorms and the FFN — three quarters of
+    the block's GEMM work — run on the R kept rows only, and the block returns [R, D] in ``keep_rows`` order.
+    Exact: the dropped rows' outputs are dead values in the reference too."""
     xd = x.data
     kw = spec.kwargs()
     s_attn, s_o, s_act, s_f2 = (tape.next_seed() for _ in range(4))
     akw = dict(drop_p=p_attn, drop_seed=s_attn)
+    R = None if keep_rows is None else int(keep_rows.numel())
+
+    def gather(src):
+        """rows ``keep_rows`` of src (identity when the block keeps everything)"""
+        if keep_rows is None:
+            return src
+        out_ = torch.empty(R, src.shape[1], dtype=src.dtype, device=src.device)
+        ops.row_axpby(out_, R, a=src, ai=keep_rows)
+        return out_
+
+    def spread(g_, rows):
+        """adjoint of gather: a [rows, D] tensor that is zero except g_ at ``keep_rows``"""
+        if keep_rows is None:
+            return g_
+        full = torch.zeros(rows, g_.shape[1], dtype=g_.dtype, device=g_.device)
+        ops.row_axpby(full, R, di=keep_rows, a=g_)
+        return full
+
     if not pre_ln:
         qkv = ops.gemm(xd, P.qkv_w.data, bias=P.qkv_b.data)
-        ctx, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw, **akw)
-        t = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xd, drop_p=p_hidden, drop_seed=s_o)
+        ctx_full, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw, **akw)
+        ctx, xk = gather(ctx_full), gather(xd)
+        t = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xk, drop_p=p_hidden, drop_seed=s_o)
         a, m1, r1 = ops.layernorm_fwd(t, P.ln1_w.data, P.ln1_b.data, eps)
         u = torch.empty(a.shape[0], P.fc1_w.shape[0], dtype=a.dtype, device=a.device)
         h = ops.gemm(a, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act)
@@ -203,8 +228,9 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
     else:
         n1, m1, r1 = ops.layernorm_fwd(xd, P.ln1_w.data, P.ln1_b.data, eps)
         qkv = ops.gemm(n1, P.qkv_w.data, bias=P.qkv_b.data)
-        ctx, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw, **akw)
-        hmid = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xd, drop_p=p_hidden, drop_seed=s_o)
+        ctx_full, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw, **akw)
+        ctx, xk = gather(ctx_full), gather(xd)
+        hmid = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xk, drop_p=p_hidden, drop_seed=s_o)
         n2, m2, r2 = ops.layernorm_fwd(hmid, P.ln2_w.data, P.ln2_b.data, eps)
         u = torch.empty(n2.shape[0], P.fc1_w.shape[0], dtype=n2.dtype, device=n2.device)
         f = ops.gemm(n2, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act)
@@ -221,7 +247,7 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
             extra = dict(d_sp_table=tape.pgrad(spec.sp_table),
                          d_virt=None if tape.pgrad(spec.virt) is None else tape.pgrad(spec.virt).view(-1))
         want_dense = spec.dense_bias_var is not None and spec.dense_bias_var.needs_grad
-        dqkv, dbias = ops.attention_bwd(dctx, qkv, ctx, lse, spec.nseq, spec.S, spec.H, **kw,
+        dqkv, dbias = ops.attention_bwd(spread(dctx, xd.shape[0]), qkv, ctx_full, lse, spec.nseq, spec.S, spec.H, **kw,
                                         want_dense_dbias=want_dense, **extra, **akw)
         if want_dense:
             tape.add_grad(spec.dense_bias_var, dbias)
@@ -245,7 +271,7 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         dqkv = attn_bwd(dctx)
         wgrad(tape, dqkv, xd, P.qkv_w, P.qkv_b)
         if x.needs_grad:
-            tape.add_grad(x, ops.gemm(dqkv, P.qkv_w.data, trans_b=True, residual=dt_))
+            tape.add_grad(x, ops.gemm(dqkv, P.qkv_w.data, trans_b=True, residual=spread(dt_, xd.shape[0])))
         if tape.on_params_ready:
             tape.on_params_ready(P.all())
 
@@ -268,7 +294,7 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         wgrad(tape, dqkv, n1, P.qkv_w, P.qkv_b)
         if x.needs_grad:
             dn1 = ops.gemm(dqkv, P.qkv_w.data, trans_b=True)
-            tape.add_grad(x, _ln_bwd(tape, dn1, xd, P.ln1_w, P.ln1_b, m1, r1, add=dh))
+            tape.add_grad(x, _ln_bwd(tape, dn1, xd, P.ln1_w, P.ln1_b, m1, r1, add=spread(dh, xd.shape[0])))
         else:   # LayerNorm parameters still need their gradients
             dn1 = ops.gemm(dqkv, P.qkv_w.data, trans_b=True)
             _ln_bwd(tape, dn1, xd, P.ln1_w, P.ln1_b, m1, r1)

@@ -156,9 +156,8 @@ class GraphormerEncoder(nn.Module):
         nb = ge.num_bottle_neck
 
         def run(tape):
-            text, glob = ge._fwd(tape, pb)
-            ix = ge._indices(pb)
-            logits = E.classifier_head(tape, text, pb.M, ix["cls_rows"], ix["bn0_rows"], ge.text_pooler.dense.weight,
+            text, glob, rows = ge._fwd(tape, pb, prune_last=ge.prune_last_layer)
+            logits = E.classifier_head(tape, text, pb.M, rows["cls_rows"], rows["bn0_rows"], ge.text_pooler.dense.weight,
                                        ge.text_pooler.dense.bias, ge.node_classifier.weight, ge.node_classifier.bias,
                                        p_drop=p_head)
             return logits, glob

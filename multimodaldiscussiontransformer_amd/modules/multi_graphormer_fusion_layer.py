@@ -41,21 +41,30 @@ class GraphFusionLayer(nn.Module):
         return list(self.bert_encoder.parameters()) + list(self.vit_encoder.parameters())
 
     def _fwd(self, tape, text: E.Var, vit: Optional[E.Var], M: int, text_spec: dict, I: int, Sv: int,
-             img_text_bn_rows, vit_bn_rows):
+             img_text_bn_rows, vit_bn_rows, prune: Optional[dict] = None):
         """text [rows, D] (padded: M*(nb+L) rows + key mask; ragged: valid tokens only + sequence offsets — both
         described by ``text_spec`` = AttnSpec keywords), vit [I*Sv, D] or None.  ``img_text_bn_rows`` /
-        ``vit_bn_rows``: i32[I*nb] row indices of the bottleneck tokens of image comments in the text / image buffers."""
+        ``vit_bn_rows``: i32[I*nb] row indices of the bottleneck tokens of image comments in the text / image buffers.
+        ``prune`` (the LAST fusion layer of the logits path): dict(text_keep i32[2M] = rows of bottleneck token 0 and
+        [CLS] of every comment, vit_keep i32[I] = bottleneck-0 row of every image, img_bn0_compact i32[I] = row of
+        that comment's bottleneck token 0 in the compact text output).  Both blocks then run their output projection,
+        LayerNorms and FFN on the kept rows only and return compact [2M, D] / [I, D] tensors."""
         nb = self.num_bottle_neck_tokens
         be, ve = self.bert_encoder, self.vit_encoder
         if vit is not None:
             E.rows_mix(tape, vit, text, I * nb, alpha=1.0, beta=0.0, d_idx=vit_bn_rows, s_idx=img_text_bn_rows)
         spec_t = E.AttnSpec(nseq=M, H=be.heads, **text_spec)
-        text_out = E.transformer_block(tape, text, be.block_params(), spec_t, pre_ln=False, eps=be.eps, **be.drop_kwargs())
+        text_out = E.transformer_block(tape, text, be.block_params(), spec_t, pre_ln=False, eps=be.eps, **be.drop_kwargs(),
+                                       keep_rows=None if prune is None else prune["text_keep"])
         vit_out = None
         if vit is not None:
             spec_v = E.AttnSpec(nseq=I, S=Sv, H=ve.heads)
-            vit_out = E.transformer_block(tape, vit, ve.block_params(), spec_v, pre_ln=True, eps=ve.eps, **ve.drop_kwargs())
-            E.rows_mix(tape, text_out, vit_out, I * nb, alpha=0.5, beta=0.5, d_idx=img_text_bn_rows, s_idx=vit_bn_rows)
+            vit_out = E.transformer_block(tape, vit, ve.block_params(), spec_v, pre_ln=True, eps=ve.eps, **ve.drop_kwargs(),
+                                          keep_rows=None if prune is None else prune["vit_keep"])
+            if prune is None:
+                E.rows_mix(tape, text_out, vit_out, I * nb, alpha=0.5, beta=0.5, d_idx=img_text_bn_rows, s_idx=vit_bn_rows)
+            else:   # only bottleneck token 0 is read after the last fusion layer
+                E.rows_mix(tape, text_out, vit_out, I, alpha=0.5, beta=0.5, d_idx=prune["img_bn0_compact"])
         return text_out, vit_out
 
     def forward(self, bert_hidden_states: torch.Tensor, vit_hidden_states: torch.Tensor, bottle_neck: torch.Tensor,
@@ -109,9 +118,10 @@ class GraphFusionStack(nn.Module):
         self.fusion_layers = nn.ModuleList([
             GraphFusionLayer(b, v, num_bottle_neck_tokens, use_projection) for b, v in zip(bert_layers, vit_layers)])
 
-    def _fwd(self, tape, text, vit, *a):
-        for f in self.fusion_layers:
-            text, vit = f._fwd(tape, text, vit, *a)
+    def _fwd(self, tape, text, vit, *a, prune=None):
+        n = len(self.fusion_layers)
+        for k, f in enumerate(self.fusion_layers):
+            text, vit = f._fwd(tape, text, vit, *a, prune=prune if k == n - 1 else None)
         return text, vit
 
     def forward(self, bert_hidden_states, vit_hidden_states, bottle_neck, bert_attention_mask=None, x_image_indexes=None):

@@ -120,6 +120,9 @@ class MultiGraphormerGraphEncoder(nn.Module):
         # valid-token packing of the text side (see _indices); MDT_DENSE_TOKENS=1 or ``ragged_tokens = False`` runs
         # the padded layout, which also reproduces the reference's hidden states at padded positions
         self.ragged_tokens = os.environ.get("MDT_DENSE_TOKENS", "0") != "1"
+        # logits path only (GraphormerModel.forward): the last fusion layer computes just the rows that are read
+        # afterwards; MDT_FULL_LAST_LAYER=1 or ``prune_last_layer = False`` computes every row as the reference does
+        self.prune_last_layer = os.environ.get("MDT_FULL_LAST_LAYER", "0") != "1"
 
         def set_grad(m, flag):
             if m is not None:
@@ -223,8 +226,11 @@ class MultiGraphormerGraphEncoder(nn.Module):
         return idx
 
     # ------------------------------------------------------------------ tape-level forward
-    def _fwd(self, tape, pb: PackedBatch):
-        """→ (text buffer Var [rows_fus, D] in the layout of ``_indices``, global embedding Var [B, D])."""
+    def _fwd(self, tape, pb: PackedBatch, prune_last: bool = False):
+        """→ (text buffer Var, global embedding Var [B, D], rows) where ``rows`` = dict(bn0_rows, cls_rows) locates
+        bottleneck token 0 and [CLS] of every comment in the returned text buffer: the [rows_fus, D] layout of
+        ``_indices``, or — ``prune_last``, the logits path — the compact [2M, D] output of a last fusion layer that
+        computed only those two rows per comment (engine.transformer_block ``keep_rows``)."""
         tr = self.training
         p_emb = self.activation_dropout_p if tr else 0.0     # HF hidden_dropout_prob := act_dropout (:238,:243)
         nb = self.num_bottle_neck
@@ -273,16 +279,36 @@ class MultiGraphormerGraphEncoder(nn.Module):
                            spatial_pos=pb.spatial_pos, sp_table=gab.spatial_pos_encoder.weight,
                            virt=gab.graph_token_virtual_distance.weight, key_pad=pb.key_pad)
         F = len(self.fusion_layers)
+        rows = dict(bn0_rows=ix["bn0_rows"], cls_rows=ix["cls_rows"])
         for st in range(F - 1):                       # zip(self.layers, self.fusion_layers[1:])  (:413)
             x = self.layers[st]._fwd(tape, x, gspec)
             # bottle_neck[:, 0, :] = x[mask]  (:425)
             E.rows_mix(tape, text, x, M, alpha=1.0, beta=0.0, d_idx=ix["bn0_rows"], s_idx=pb.graph_row)
-            text, vit = self.fusion_layers[st + 1]._fwd(tape, text, vit, *fargs)
+            prune = None
+            if prune_last and st == F - 2:
+                # after the last fusion layer only bottleneck token 0 (graph copy-back, head) and [CLS] (head) of each
+                # comment are ever read: compute just those rows there
+                prune, rows = self._prune_indices(pb, ix)
+            text, vit = self.fusion_layers[st + 1]._fwd(tape, text, vit, *fargs, prune=prune)
             # x[mask] = bottle_neck[:, 0, :]  (:435)
-            E.rows_mix(tape, x, text, M, alpha=1.0, beta=0.0, d_idx=pb.graph_row, s_idx=ix["bn0_rows"])
+            E.rows_mix(tape, x, text, M, alpha=1.0, beta=0.0, d_idx=pb.graph_row, s_idx=rows["bn0_rows"])
         x = self.layers[-1]._fwd(tape, x, gspec)       # layers[F]; layers[F-1] is never executed (quirk 3)
         glob = E.take_rows(tape, x, B, s_map=(1, T, 0))
-        return text, glob
+        return text, glob, rows
+
+    def _prune_indices(self, pb: PackedBatch, ix):
+        key = ("prune_idx", self.num_bottle_neck, bool(self.ragged_tokens))
+        if key not in pb.extras:
+            dev = pb.ids.device
+            i32 = dict(device=dev, dtype=torch.int32)
+            m_ar = torch.arange(pb.M, **i32)
+            text_keep = torch.stack([ix["bn0_rows"], ix["cls_rows"]], dim=1).reshape(-1).contiguous()     # 2m, 2m+1
+            prune = dict(text_keep=text_keep,
+                         vit_keep=(torch.arange(pb.I, **i32) * ix["Sv"]).contiguous(),
+                         img_bn0_compact=(pb.img_comment * 2).contiguous())
+            rows = dict(bn0_rows=(m_ar * 2).contiguous(), cls_rows=(m_ar * 2 + 1).contiguous())
+            pb.extras[key] = (prune, rows)
+        return pb.extras[key]
 
     def live_parameters(self):
         seen, out = set(), []
@@ -301,7 +327,7 @@ class MultiGraphormerGraphEncoder(nn.Module):
         nb = self.num_bottle_neck
 
         def run(tape):
-            text, glob = self._fwd(tape, pb)
+            text, glob, _ = self._fwd(tape, pb)
             return text, glob
 
         ix = self._indices(pb)
@@ -314,7 +340,7 @@ class MultiGraphormerGraphEncoder(nn.Module):
         # ragged tape: give the caller the reference's padded shapes; rows of padded positions (which the
         # reference fills with the hidden states of padding tokens, never read by mDT) are zero
         def run_padded(tape):
-            text, glob = self._fwd(tape, pb)
+            text, glob, _ = self._fwd(tape, pb)
             rt = get_ragged(pb)
             dense_rows = (rt.comment * pb.L + rt.pos).contiguous()
             fus_rows = ix["pre2fus"]

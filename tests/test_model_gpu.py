@@ -274,6 +274,37 @@ def test_ragged_tokens_equal_padded_tokens_fp32():
         torch.testing.assert_close(g1[n], g0[n], atol=2e-5 * max(1.0, float(g0[n].abs().max())), rtol=1e-4, msg=n)
 
 
+@pytest.mark.parametrize("kind", ["A", "B"])
+def test_pruned_last_fusion_layer_equals_full_fp32(kind):
+    """The logits path computes only bottleneck token 0 and [CLS] of every comment in the LAST fusion layer (the
+    other rows' outputs are dead values in the reference): logits, loss and every gradient equal the full computation."""
+    from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
+    from multimodaldiscussiontransformer_amd.data.packer import pack_batch
+    from multimodaldiscussiontransformer_amd.models import GraphormerModel
+    hp = cases.tiny_hparams(kind)
+    trees = cases.tiny_trees(kind, hp)
+    res = {}
+    for prune in (False, True):
+        model = GraphormerModel.build_model(model_args(hp), task=None)
+        fill_hash_weights(model)
+        model = model.cuda().eval()
+        model.encoder.graph_encoder.prune_last_layer = prune
+        pb = pack_batch(trees, 5)
+        crit = GraphPredictionNodeCrossEntropy(None, positive_weight=1.5, negative_weight=1.0)
+        loss, _, _ = crit(model, {"nsamples": len(trees), "net_input": {"batched_data": pb.batched_data}})
+        loss.backward()
+        with torch.no_grad():
+            logits, glob = model(pb.batched_data)
+        res[prune] = (float(loss.detach()), logits.cpu(), glob.cpu(), {n: p.grad.cpu() for n, p in model.named_parameters() if p.grad is not None})
+    (l0, lg0, gl0, g0), (l1, lg1, gl1, g1) = res[False], res[True]
+    assert abs(l0 - l1) < 1e-5
+    torch.testing.assert_close(lg1, lg0, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(gl1, gl0, atol=2e-5, rtol=1e-5)
+    assert set(g0) == set(g1)
+    for n in g0:
+        torch.testing.assert_close(g1[n], g0[n], atol=2e-5 * max(1.0, float(g0[n].abs().max())), rtol=1e-4, msg=n)
+
+
 def test_tree_permutation_and_node_padding_invariance_fp32():
     """SURVEY.md §4 property tests: (a) permuting the trees of a batch permutes the per-comment logits and leaves
     the loss and every parameter gradient unchanged; (b) adding a larger tree to the batch (more node padding N,
