@@ -144,6 +144,10 @@ typedef struct {
                                  consecutive rows starting at row off[s] (seq_stride unused, pos_stride must be 1, no masks /
                                  biases: every packed token is valid).  S stays the bound that sizes lse [nseq,H,S] and the
                                  dropout counters.  This is how padded token positions of a comment batch are never computed. */
+  int q_limit;                /* 0 = every query row.  n > 0: only the first n rows of each sequence are needed as QUERIES
+                                 (keys / values are always the whole sequence): forward leaves `out` / `lse` of the other rows
+                                 unspecified, backward assumes their `dout` is zero and returns dQ = 0 for them.  Kernels may
+                                 round n up (they work in 16-row tiles) or ignore it. */
 } mdt_attn_fwd_args;
 int mdt_attention_fwd(void* stream, const mdt_attn_fwd_args* a);
 

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(AttnParams P) {
   const int drop_bh = seq * a.H + h;   // counters: attention_common.hpp
   const float scale2 = a.scale * LOG2E;
   const int g = lane >> 4, c = lane & 15;
-  const int n_qt = (S + 15) >> 4;
+  int n_qt = (S + 15) >> 4;
+  if (a.q_limit > 0 && ((a.q_limit + 15) >> 4) < n_qt) n_qt = (a.q_limit + 15) >> 4;   // only these query tiles are needed
   for (int qt = wave; qt < n_qt; qt += 4) {
     const int q0 = qt * 16;
     const int q = q0 + c;
@@ -428,7 +429,9 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
   for (int i = tid; i < s_live; i += 256) {
     s_kb[i] = key_only_bias<bf16_t>(bc, i);
     float l = -INFINITY, de = 0.f;
-    if (i < S) {
+    // rows beyond q_limit were not computed by the forward pass (out / lse unspecified) and carry no gradient:
+    // treat them like rows past the end (lse -> +inf below, so every p of theirs is 0)
+    if (i < S && (a.q_limit <= 0 || i < ((a.q_limit + 15) & ~15))) {
       l = a.lse[((int64_t)seq * a.H + h) * SL + i];
 #pragma unroll
       for (int c8 = 0; c8 < HD / 8; ++c8) {
@@ -449,9 +452,13 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
   const int g = lane >> 4, c = lane & 15;
   const int n_t = (S + 15) >> 4;
   const int n_chunk = s_live >> 6;          // 64-wide chunks
+  // q_limit: queries beyond it carry no gradient (dout = 0, dQ = 0): pass A visits only the needed query tiles, pass B
+  // sums over the query chunks that contain them
+  const int n_tq = (a.q_limit > 0 && ((a.q_limit + 15) >> 4) < n_t) ? (a.q_limit + 15) >> 4 : n_t;
+  const int n_chunk_q = (a.q_limit > 0 && ((a.q_limit + 63) >> 6) < n_chunk) ? (a.q_limit + 63) >> 6 : n_chunk;
 
   // ------------------------------------------------------------------ pass A (queries on lanes)
-  for (int qt = wave; qt < n_t; qt += 4) {
+  for (int qt = wave; qt < n_tq; qt += 4) {
     const int q0 = qt * 16;
     const int q = q0 + c;
     const bool qok = q < S;
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
     f32x4 dv[ND], dk[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) { dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    for (int ch = 0; ch < n_chunk; ++ch) {
+    for (int ch = 0; ch < n_chunk_q; ++ch) {
       const int t0 = ch * 4;
       f32x4 sc[4], dp[4];
 #pragma unroll

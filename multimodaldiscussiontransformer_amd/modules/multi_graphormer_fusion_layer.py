@@ -53,12 +53,13 @@ class GraphFusionLayer(nn.Module):
         be, ve = self.bert_encoder, self.vit_encoder
         if vit is not None:
             E.rows_mix(tape, vit, text, I * nb, alpha=1.0, beta=0.0, d_idx=vit_bn_rows, s_idx=img_text_bn_rows)
-        spec_t = E.AttnSpec(nseq=M, H=be.heads, **text_spec)
+        # pruned layer: the kept rows (bottleneck 0, [CLS]) are among the first nb + 1 rows of a comment, row 0 of an image
+        spec_t = E.AttnSpec(nseq=M, H=be.heads, q_limit=0 if prune is None else nb + 1, **text_spec)
         text_out = E.transformer_block(tape, text, be.block_params(), spec_t, pre_ln=False, eps=be.eps, **be.drop_kwargs(),
                                        keep_rows=None if prune is None else prune["text_keep"])
         vit_out = None
         if vit is not None:
-            spec_v = E.AttnSpec(nseq=I, S=Sv, H=ve.heads)
+            spec_v = E.AttnSpec(nseq=I, S=Sv, H=ve.heads, q_limit=0 if prune is None else 1)
             vit_out = E.transformer_block(tape, vit, ve.block_params(), spec_v, pre_ln=True, eps=ve.eps, **ve.drop_kwargs(),
                                           keep_rows=None if prune is None else prune["vit_keep"])
             if prune is None:

@@ -100,8 +100,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, add=None, dgamma=None, dbeta=None, d
 
 
 def _attn_args(qkv, out, lse, nseq, S, H, hd, seq_stride, pos_stride, scale, key_mask, dense_bias, attn_bias,
-               spatial_pos, sp_table, virt, key_pad, drop_p=0.0, drop_seed=0, seq_offsets=None):
+               spatial_pos, sp_table, virt, key_pad, drop_p=0.0, drop_seed=0, seq_offsets=None, q_limit=0):
     a = L.AttnFwdArgs()
+    a.q_limit = int(q_limit)
     a.drop_p, a.drop_seed = float(drop_p), int(drop_seed)
     assert seq_offsets is None or (seq_offsets.dtype == torch.int32 and seq_offsets.is_contiguous() and
                                    seq_offsets.numel() == nseq + 1), "attention: seq_offsets must be i32[nseq + 1]"
@@ -128,30 +129,37 @@ def _attn_args(qkv, out, lse, nseq, S, H, hd, seq_stride, pos_stride, scale, key
 
 def attention_fwd(qkv, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None, key_mask=None, dense_bias=None,
                   attn_bias=None, spatial_pos=None, sp_table=None, virt=None, key_pad=None, drop_p=0.0, drop_seed=0,
-                  seq_offsets=None):
-    """qkv [rows, 3*D] → (out [rows, D], lse f32[nseq, H, S]).  ``seq_offsets`` i32[nseq+1]: ragged sequences
+                  seq_offsets=None, q_limit=0):
+    """qkv [rows, 3*D] → (out [rows, D], lse f32[nseq, H, S]).  ``q_limit`` > 0: only the first q_limit rows of every
+    sequence are needed as queries (other rows of out / lse unspecified).  ``seq_offsets`` i32[nseq+1]: ragged sequences
     (sequence s = rows off[s]..off[s+1], at most S of them), see include/mdt_hip.h."""
     D = qkv.shape[1] // 3
     hd = D // H
-    out = torch.empty(qkv.shape[0], D, dtype=qkv.dtype, device=qkv.device)   # every row belongs to a sequence
-    lse = torch.empty(nseq, H, S, dtype=torch.float32, device=qkv.device)
+    if q_limit:
+        # rows the kernel may skip must still read as "no contribution" for any backward kernel: out = 0, lse = +inf
+        out = torch.zeros(qkv.shape[0], D, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.full((nseq, H, S), float("inf"), dtype=torch.float32, device=qkv.device)
+    else:
+        out = torch.empty(qkv.shape[0], D, dtype=qkv.dtype, device=qkv.device)   # every row belongs to a sequence
+        lse = torch.empty(nseq, H, S, dtype=torch.float32, device=qkv.device)
     a = _attn_args(qkv, out, lse, nseq, S, H, hd, S if seq_stride is None else seq_stride, pos_stride,
                    hd ** -0.5 if scale is None else scale, key_mask, dense_bias, attn_bias, spatial_pos, sp_table,
-                   virt, key_pad, drop_p, drop_seed, seq_offsets)
+                   virt, key_pad, drop_p, drop_seed, seq_offsets, q_limit)
     check(lib.mdt_attention_fwd(stream(), C.byref(a)), "mdt_attention_fwd")
     return out, lse
 
 
 def attention_bwd(dout, qkv, out, lse, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None, key_mask=None,
                   dense_bias=None, attn_bias=None, spatial_pos=None, sp_table=None, virt=None, key_pad=None,
-                  want_dense_dbias=False, d_sp_table=None, d_virt=None, drop_p=0.0, drop_seed=0, seq_offsets=None):
+                  want_dense_dbias=False, d_sp_table=None, d_virt=None, drop_p=0.0, drop_seed=0, seq_offsets=None, q_limit=0):
     D = qkv.shape[1] // 3
     hd = D // H
-    dqkv = torch.empty_like(qkv)
+    # with q_limit the kernels skip the query rows beyond it: their dQ must read as zero
+    dqkv = torch.zeros_like(qkv) if q_limit else torch.empty_like(qkv)
     b = L.AttnBwdArgs()
     b.f = _attn_args(qkv, out, lse, nseq, S, H, hd, S if seq_stride is None else seq_stride, pos_stride,
                      hd ** -0.5 if scale is None else scale, key_mask, dense_bias, attn_bias, spatial_pos, sp_table,
-                     virt, key_pad, drop_p, drop_seed, seq_offsets)
+                     virt, key_pad, drop_p, drop_seed, seq_offsets, q_limit)
     b.dout, b.ld_dout = ptr(dout), _2d(dout)
     b.dqkv, b.ld_dqkv = ptr(dqkv), _2d(dqkv)
     dbias = None

@@ -474,3 +474,25 @@ def test_attention_ragged_sequences_equal_masked_padding(ops, dtype, bwd, Smax, 
         torch.testing.assert_close(out_r[off[s_]:off[s_] + n].float().cpu(), out_p[s_, :n], **tol)
         torch.testing.assert_close(dq_r[off[s_]:off[s_] + n].float().cpu(), dq_p[s_, :n], **tol)
         torch.testing.assert_close(lse_r[s_, :, :n].cpu(), lse_p[s_, :, :n].cpu(), atol=1e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("S,H,qlim", [(104, 3, 5), (201, 2, 1), (40, 2, 17)])
+def test_attention_query_limit(ops, dtype, S, H, qlim):
+    """q_limit: only the first rows of each sequence are needed as queries (keys / values stay the whole sequence);
+    outputs of those rows, and the gradients when dout is zero elsewhere, equal the unrestricted call."""
+    nseq, hd, p, seed = 3, 64, 0.2, 77
+    D = H * hd
+    qkv = dev(rnd(nseq * S, 3 * D, seed=5).to(dtype))
+    dout = rnd(nseq, S, D, seed=6).to(dtype)
+    dout[:, qlim:] = 0
+    dout = dev(dout.view(nseq * S, D))
+    kw = dict(drop_p=p, drop_seed=seed)
+    o_full, l_full = ops.attention_fwd(qkv, nseq, S, H, **kw)
+    g_full, _ = ops.attention_bwd(dout, qkv, o_full, l_full, nseq, S, H, **kw)
+    o_lim, l_lim = ops.attention_fwd(qkv, nseq, S, H, q_limit=qlim, **kw)
+    g_lim, _ = ops.attention_bwd(dout, qkv, o_lim, l_lim, nseq, S, H, q_limit=qlim, **kw)
+    tol = dict(atol=1e-5, rtol=1e-5) if dtype == torch.float32 else dict(atol=1e-2, rtol=1e-2)
+    torch.testing.assert_close(o_lim.view(nseq, S, D)[:, :qlim].float(), o_full.view(nseq, S, D)[:, :qlim].float(), **tol)
+    torch.testing.assert_close(l_lim[:, :, :qlim], l_full[:, :, :qlim], atol=1e-4, rtol=1e-5)
+    torch.testing.assert_close(g_lim.float(), g_full.float(), **tol)
