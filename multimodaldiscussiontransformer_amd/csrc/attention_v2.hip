@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
 //   pass A (queries on lanes): for each key chunk: S^T, dP^T -> dS^T -> dQ^T += K^T dS^T
 //   pass B (keys on lanes):    for each query chunk: S, dP -> P, dS -> dV^T += dO^T P, dK^T += Q^T dS
 template <int HD, bool STRUCT, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pad) {
+__device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad) {
   constexpr int ND = HD / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mdt_attn_fwd_args& a = P.f;
@@ -641,6 +641,17 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
   }
 }
 
+template <int HD, bool STRUCT, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pad) {
+  attn_bwd_v3_body<HD, STRUCT, DROP>(P, s_pad);
+}
+// Short sequences (S <= 128: 38 KB of LDS, four workgroups fit a CU): the same body held to 128 registers (a handful
+// spill) so that four waves per SIMD are resident — the ragged BERT sequences are latency-bound, not register-bound.
+template <int HD, bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_v3_occ4_kernel(AttnParams P, int s_pad) {
+  attn_bwd_v3_body<HD, false, DROP>(P, s_pad);
+}
+
 template <bool STRUCT, bool DROP>
 static int launch_v3(hipStream_t st, const AttnParams& p) {
   const int s_pad = (p.f.S + 63) & ~63;
@@ -653,6 +664,12 @@ static int launch_v3(hipStream_t st, const AttnParams& p) {
       (void)hipGetLastError();
       set_error("attention_bwd_v3: cannot reserve %zu bytes of LDS", lds);
       return MDT_ERR_LAUNCH;
+    }
+  }
+  if constexpr (!STRUCT) {
+    if (s_pad <= 128 && getenv("MDT_ATTN_NO_OCC4") == nullptr) {
+      hipLaunchKernelGGL((attn_bwd_v3_occ4_kernel<64, DROP>), dim3(p.f.H, p.f.nseq), 256, lds, st, p, s_pad);
+      return check_launch("attention_bwd_v3_occ4");
     }
   }
   hipLaunchKernelGGL(kern, dim3(p.f.H, p.f.nseq), 256, lds, st, p, s_pad);
