@@ -85,12 +85,17 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // v_rcp_f32 / v_exp_f32 instructions — ~15 VALU issues instead of erff's ~34, and GELU' reuses the same
 // exponential (exp(-z^2) with z = |x|/sqrt(2) is the Gaussian pdf factor).  The fp32 parity path keeps erff.
 __device__ __forceinline__ void gelu_fast_parts(float x, float& cdf, float& pdf) {
+  // explicit FMAs: the build runs with -ffp-contract=off (the fp32 parity path wants separately rounded mul / add),
+  // which would otherwise turn this Horner chain into 2 instructions per term
   const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-  const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float erf_abs = 1.0f - poly * e;
-  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+  float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+  poly = __builtin_fmaf(t, poly, 1.421413741f);
+  poly = __builtin_fmaf(t, poly, -0.284496736f);
+  poly = __builtin_fmaf(t, poly, 0.254829592f);
+  const float erf_abs = __builtin_fmaf(-(poly * t), e, 1.0f);
+  cdf = __builtin_fmaf(0.5f, copysignf(erf_abs, x), 0.5f);
   pdf = 0.3989422804014327f * e;
 }
 __device__ __forceinline__ float gelu_fast(float x) {

@@ -281,7 +281,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
     const f32x4 hi = *(const f32x4*)(ws + row * 64 + c8 + 4);
     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
+    for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], p.alpha, bias[e]);
     if ((ep & MDT_EPI_GELU) && (ep & MDT_EPI_AUX_GRAD)) {
       float sc8[8];
 #pragma unroll
@@ -425,7 +425,7 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
       if (!live) continue;
       const int64_t gc = gcs[jp];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[jp][e];
+      for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], p.alpha, bias[jp][e]);
       if ((ep & MDT_EPI_GELU) && (ep & MDT_EPI_AUX_GRAD)) {
         // value and derivative from the same exponential; the dropout scale goes into both, so backward is one multiply
         float sc8[8];
