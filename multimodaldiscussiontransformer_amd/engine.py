@@ -39,8 +39,9 @@ class Var:
 
 
 class Tape:
-    def __init__(self, use_main_grad: bool = False, on_params_ready: Optional[Callable] = None):
+    def __init__(self, use_main_grad: bool = False, on_params_ready: Optional[Callable] = None, inference: bool = False):
         self.ops: List[Callable[[], None]] = []
+        self.inference = inference                 # forward only (torch.no_grad): adjoints and what they hold are dropped
         self.use_main_grad = use_main_grad
         self.tmp_grads = {}
         self.on_params_ready = on_params_ready     # DDP hook: called with the params an op just finished
@@ -56,7 +57,8 @@ class Tape:
 
     # -- gradient plumbing ------------------------------------------------------------
     def record(self, bwd: Callable[[], None]):
-        self.ops.append(bwd)
+        if not self.inference:                     # the closure keeps every saved activation alive
+            self.ops.append(bwd)
 
     def pgrad(self, p: torch.nn.Parameter) -> Optional[torch.Tensor]:
         """fp32 accumulation buffer of a parameter, or None when it is frozen."""
@@ -680,14 +682,14 @@ def scatter_rows(tape: Tape, src: Var, rows_out: int, d_idx, s_idx) -> Var:
 class TapeFunction(torch.autograd.Function):
     """One autograd node around a whole tape.
 
-    ``TapeFunction.apply(run, use_main_grad, hook, n_in, *tensors)`` where ``tensors`` are the
+    ``TapeFunction.apply(run, use_main_grad, hook, inference, n_in, *tensors)`` where ``tensors`` are the
     ``n_in`` differentiable tensor inputs followed by every parameter the tape may touch;
     ``run(tape, *input_vars) -> tuple[Var]``."""
 
     @staticmethod
-    def forward(ctx, run, use_main_grad, hook, n_in, *tensors):
+    def forward(ctx, run, use_main_grad, hook, inference, n_in, *tensors):
         ctx.set_materialize_grads(False)
-        tape = Tape(use_main_grad=use_main_grad, on_params_ready=hook)
+        tape = Tape(use_main_grad=use_main_grad, on_params_ready=hook, inference=inference)
         ins = [Var(t, needs_grad=t.requires_grad) for t in tensors[:n_in]]
         outs = run(tape, *ins)
         ctx.tape, ctx.ins, ctx.outs = tape, ins, outs
@@ -712,7 +714,7 @@ class TapeFunction(torch.autograd.Function):
                 g = tape.tmp_grads.get(id(p))
                 gp.append(None if g is None else (g if p.dtype == torch.float32 else ops.cast(g, p.dtype)))
         ctx.tape = ctx.ins = ctx.outs = None
-        return (None, None, None, None, *gin, *gp)
+        return (None, None, None, None, None, *gin, *gp)
 
 
 def run_tape(run, inputs: Sequence[torch.Tensor], params: Sequence[torch.nn.Parameter], *, use_main_grad=False, hook=None):
@@ -720,4 +722,6 @@ def run_tape(run, inputs: Sequence[torch.Tensor], params: Sequence[torch.nn.Para
     probe = inputs[0] if len(inputs) else params[0]
     if not probe.is_cuda:
         raise RuntimeError("the mDT HIP path has no CPU fallback: move the module and its inputs to the GPU")
-    return TapeFunction.apply(run, use_main_grad, hook, len(inputs), *inputs, *params)
+    # grad mode is read HERE: inside Function.forward it is always off
+    inference = not torch.is_grad_enabled()
+    return TapeFunction.apply(run, use_main_grad, hook, inference, len(inputs), *inputs, *params)
