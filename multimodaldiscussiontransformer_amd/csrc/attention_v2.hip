@@ -91,6 +91,21 @@ __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(AttnParams P) {
   // (unguarded: a guard there costs the compiler 80 registers) MFMA loop as exact zeros and every later
   // per-element stage skips them, so they cost LDS reads and idle MFMA slots but no VALU work.
   const int ntk = (S + 15) >> 4;
+  // The Q fragments of every query tile this wave will visit are requested BEFORE K / V are staged, so their global
+  // latency overlaps the staging (measured: the waves of this kernel sat in s_waitcnt / s_barrier 68 % of their
+  // cycles, mostly on the per-tile Q loads).  A wave owns tiles wave, wave + 4, ... : at most MAXT of them.
+  constexpr int MAXT = (NT + 3) / 4;
+  int n_qt = (S + 15) >> 4;
+  if (a.q_limit > 0 && ((a.q_limit + 15) >> 4) < n_qt) n_qt = (a.q_limit + 15) >> 4;   // only these query tiles are needed
+  bf16x8 fq_all[MAXT][HD / 32];
+#pragma unroll
+  for (int k = 0; k < MAXT; ++k) {
+    const int qt_k = wave + 4 * k;
+    if (qt_k < n_qt) {
+#pragma unroll
+      for (int ks = 0; ks < HD / 32; ++ks) fq_all[k][ks] = v2_frag_glb(qkv, tld, S, qt_k * 16, ks * 32, lane);
+    }
+  }
   v2_stage<HD>(imgK, qkv + D, tld, S, S_PAD, tid);
   v2_stage<HD>(imgV, qkv + 2 * D, tld, S, S_PAD, tid);
   for (int i = tid; i < S_PAD; i += 256) s_kb[i] = key_only_bias<bf16_t>(bc, i);
@@ -98,15 +113,16 @@ __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(AttnParams P) {
   const int drop_bh = seq * a.H + h;   // counters: attention_common.hpp
   const float scale2 = a.scale * LOG2E;
   const int g = lane >> 4, c = lane & 15;
-  int n_qt = (S + 15) >> 4;
-  if (a.q_limit > 0 && ((a.q_limit + 15) >> 4) < n_qt) n_qt = (a.q_limit + 15) >> 4;   // only these query tiles are needed
-  for (int qt = wave; qt < n_qt; qt += 4) {
+#pragma unroll
+  for (int k = 0; k < MAXT; ++k) {
+    const int qt = wave + 4 * k;
+    if (qt >= n_qt) break;
     const int q0 = qt * 16;
     const int q = q0 + c;
     const int qc = q < S ? q : S - 1;
     bf16x8 fq[HD / 32];
 #pragma unroll
-    for (int ks = 0; ks < HD / 32; ++ks) fq[ks] = v2_frag_glb(qkv, tld, S, q0, ks * 32, lane);
+    for (int ks = 0; ks < HD / 32; ++ks) fq[ks] = fq_all[k][ks];
     f32x4 sc[2 * NP];
 #pragma unroll
     for (int t = 0; t < 2 * NP; ++t) sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
