@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
 // kernel from 1 to 3-4 waves per SIMD — these sequences are short and the kernel is latency-bound.
 //   pass A (queries on lanes): for each key chunk: S^T, dP^T -> dS^T -> dQ^T += K^T dS^T
 //   pass B (keys on lanes):    for each query chunk: S, dP -> P, dS -> dV^T += dO^T P, dK^T += Q^T dS
-template <int HD, bool STRUCT, bool DROP>
+template <int HD, bool STRUCT, bool DROP, bool PF>   // PF: fragments of the next tile requested one tile ahead (16 more registers)
 __device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad) {
   constexpr int ND = HD / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -436,6 +436,17 @@ __device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad)
   const int nhist = STRUCT ? ((a.num_spatial + 1 + 3) & ~3) : 0;
   BiasCtx bc{seq, h, S, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
   const int s_live = (S + 63) & ~63;                    // rows this (possibly ragged) sequence really uses, in 64-key chunks
+  // Latency hiding (the waves of this kernel sat in s_waitcnt / s_barrier for half to two thirds of their cycles):
+  // the Q / dO fragments of a wave's first query tile are requested before K / V are staged, and every later
+  // tile's fragments while the previous tile is being computed; pass B treats its K / V fragments the same way.
+  bf16x8 fq_n[HD / 32], fo_n[HD / 32];
+  if constexpr (PF) {
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      fq_n[ks] = v2_frag_glb(qkv, tld, S, wave * 16, ks * 32, lane);
+      fo_n[ks] = v2_frag_glb(dout, dld, S, wave * 16, ks * 32, lane);
+    }
+  }
   v2_stage<HD>(img0, qkv + D, tld, S, s_live, tid);      // K
   v2_stage<HD>(img1, qkv + 2 * D, tld, S, s_live, tid);  // V
   // s_lse holds lse * log2(e) (+inf for rows without a finite lse, so every p of such a row is exp2(-inf) = 0);
@@ -482,8 +493,15 @@ __device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad)
     bf16x8 fq[HD / 32], fo[HD / 32];
 #pragma unroll
     for (int ks = 0; ks < HD / 32; ++ks) {
-      fq[ks] = v2_frag_glb(qkv, tld, S, q0, ks * 32, lane);
-      fo[ks] = v2_frag_glb(dout, dld, S, q0, ks * 32, lane);
+      if constexpr (PF) { fq[ks] = fq_n[ks]; fo[ks] = fo_n[ks]; }
+      else { fq[ks] = v2_frag_glb(qkv, tld, S, q0, ks * 32, lane); fo[ks] = v2_frag_glb(dout, dld, S, q0, ks * 32, lane); }
+    }
+    if (PF && qt + 4 < n_tq) {
+#pragma unroll
+      for (int ks = 0; ks < HD / 32; ++ks) {
+        fq_n[ks] = v2_frag_glb(qkv, tld, S, q0 + 64, ks * 32, lane);
+        fo_n[ks] = v2_frag_glb(dout, dld, S, q0 + 64, ks * 32, lane);
+      }
     }
     const float l2 = s_lse[qc], del = s_delta[qc];
     const uint32_t rp = attn_row_pairs(drop_bh, SL, qc) + 2 * g;
@@ -555,6 +573,14 @@ __device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad)
         *(bf16x4*)(orow + d * 16) = bf16x4{(bf16_t)(dq[d][0] * os), (bf16_t)(dq[d][1] * os), (bf16_t)(dq[d][2] * os), (bf16_t)(dq[d][3] * os)};
     }
   }
+  bf16x8 fk_n[HD / 32], fv_n[HD / 32];
+  if constexpr (PF) {
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      fk_n[ks] = v2_frag_glb(qkv + D, tld, S, wave * 16, ks * 32, lane);
+      fv_n[ks] = v2_frag_glb(qkv + 2 * D, tld, S, wave * 16, ks * 32, lane);
+    }
+  }
   __syncthreads();   // K / V images are free
   v2_stage<HD>(img0, qkv, tld, S, s_live, tid);    // Q
   v2_stage<HD>(img1, dout, dld, S, s_live, tid);   // dO
@@ -584,8 +610,15 @@ __device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad)
     bf16x8 fk[HD / 32], fv[HD / 32];
 #pragma unroll
     for (int ks = 0; ks < HD / 32; ++ks) {
-      fk[ks] = v2_frag_glb(qkv + D, tld, S, key0, ks * 32, lane);
-      fv[ks] = v2_frag_glb(qkv + 2 * D, tld, S, key0, ks * 32, lane);
+      if constexpr (PF) { fk[ks] = fk_n[ks]; fv[ks] = fv_n[ks]; }
+      else { fk[ks] = v2_frag_glb(qkv + D, tld, S, key0, ks * 32, lane); fv[ks] = v2_frag_glb(qkv + 2 * D, tld, S, key0, ks * 32, lane); }
+    }
+    if (PF && kt + 4 < n_t) {
+#pragma unroll
+      for (int ks = 0; ks < HD / 32; ++ks) {
+        fk_n[ks] = v2_frag_glb(qkv + D, tld, S, key0 + 64, ks * 32, lane);
+        fv_n[ks] = v2_frag_glb(qkv + 2 * D, tld, S, key0 + 64, ks * 32, lane);
+      }
     }
     const uint32_t kh = base_rp + (uint32_t)(key >> 1);
     f32x4 dv[ND], dk[ND];
@@ -659,13 +692,13 @@ __device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad)
 
 template <int HD, bool STRUCT, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pad) {
-  attn_bwd_v3_body<HD, STRUCT, DROP>(P, s_pad);
+  attn_bwd_v3_body<HD, STRUCT, DROP, true>(P, s_pad);
 }
 // Short sequences (S <= 128: 38 KB of LDS, four workgroups fit a CU): the same body held to 128 registers (a handful
 // spill) so that four waves per SIMD are resident — the ragged BERT sequences are latency-bound, not register-bound.
 template <int HD, bool DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_v3_occ4_kernel(AttnParams P, int s_pad) {
-  attn_bwd_v3_body<HD, false, DROP>(P, s_pad);
+  attn_bwd_v3_body<HD, false, DROP, false>(P, s_pad);   // the 128-register build has no room for the look-ahead
 }
 
 template <bool STRUCT, bool DROP>
