@@ -282,10 +282,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # rehearsal switches (not for measurements): MDT_SINGLE_DEVICE=1 puts every rank on cuda:0 and MDT_DIST_BACKEND=gloo
+    # replaces RCCL, so the whole multi-process flow can be exercised on a one-GPU box
+    if os.environ.get("MDT_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also at --nproc-per-node 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("MDT_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from multimodaldiscussiontransformer_amd import synthetic
     from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
