@@ -35,6 +35,7 @@ struct GemmParams {
   int group_n;                  // column tiles swept together before moving down the rows (ping-pong kernel's tile order)
   DropCfg drop;
   float* colsum;
+  int* tile_queue;              // persistent kernel, dynamic mode: 9 device ints (one head per XCD + finished-workgroup count), all 0 between launches
   unsigned long long* stamps;   // diagnostic (MDT_GEMM_STAMP=1): per workgroup {shader cycles, 100-MHz ticks, k-tiles} of the main loop
 };
 
@@ -922,10 +923,35 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
     const int steps = ((blockIdx.x >> 3) & 7) * (nhs / 8);
     for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(28);   // ~ one 32-k step each
   }
+  // Tile walk.  Static (tile_queue == NULL): v = blockIdx.x, + gridDim.x, ...  Dynamic: the first tile is blockIdx.x,
+  // every later one comes from a queue — one head per XCD (virtual ids v = x + 8 j keep the XCD-aware order), other
+  // XCDs' queues are raided when the own one is empty — so a CU that starts late or shares its time with another
+  // kernel (RCCL during backward) simply takes fewer tiles instead of holding the whole launch back.  Wave 0 pops the
+  // id one tile ahead (the atomic's latency hides under the epilogue) and hands it to the other waves through the one
+  // ring buffer that is idle at a tile boundary (the stage to be rewritten next), between two workgroup barriers.
+  const bool dyn = p.tile_queue != nullptr;
+  const int my_xcd = blockIdx.x & 7;
+  auto pop_tile = [&]() -> int {                 // wave 0, lane 0 only; -1 = no tile left
+    for (int k = 0; k < 8; ++k) {
+      const int x = (my_xcd + k) & 7;
+      const int cnt = (nvt - x + 7) >> 3;        // ids x, x+8, ... below nvt
+      const int j = (int)(gridDim.x >> 3) + atomicAdd(p.tile_queue + x, 1);   // the first gridDim.x ids were dealt statically
+      if (j < cnt) return x + 8 * j;
+    }
+    return -1;
+  };
+  int* slot = (int*)(smem + (PP_DIST % PP_NB) * PP_STAGE);      // idle until step 0 of the first tile issues step PP_DIST
   int v = blockIdx.x;
+  int v_next = v + (int)gridDim.x < nvt ? v + (int)gridDim.x : -1;
+  if (dyn) {
+    if (tid == 0) *slot = pop_tile();
+    __syncthreads();
+    v_next = *slot;
+    __syncthreads();
+  }
   Desc cur = make_desc(v);
-  bool has_next = v + (int)gridDim.x < nvt;
-  Desc nxt = make_desc(has_next ? v + (int)gridDim.x : v);
+  bool has_next = v_next >= 0;
+  Desc nxt = make_desc(has_next ? v_next : v);
 #pragma unroll
   for (int h = 0; h < PP_DIST; ++h) issue_step(cur, h, h);       // host guarantees nhs >= PP_DIST
   wait_pieces(PP_DIST - 1);
@@ -977,12 +1003,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
     }
     if (!late) __builtin_amdgcn_s_barrier();     // both groups leave the tile together
     if (p.stamps) { s_cyc += __builtin_amdgcn_s_memtime() - t_cyc; s_real += __builtin_amdgcn_s_memrealtime() - t_real; s_nk += nhs / 2; }
+    int popped = -1;
+    if (dyn && has_next && tid == 0) popped = pop_tile();       // the tile after next; returns while the epilogue runs
     direct_epilogue<2>(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 64);
     if (!has_next) break;
-    v += gridDim.x;
     cur = nxt;
-    has_next = v + (int)gridDim.x < nvt;
-    if (has_next) nxt = make_desc(v + (int)gridDim.x);
+    if (dyn) {
+      int* bslot = (int*)(smem + b_wr * PP_STAGE);               // the stage buffer step 0 of the next tile will rewrite
+      if (tid == 0) *bslot = popped;
+      __syncthreads();
+      v_next = *bslot;
+      __syncthreads();                                           // every wave has read it before any LDS-DMA lands there
+    } else {
+      v += gridDim.x;
+      v_next = v + (int)gridDim.x < nvt ? v + (int)gridDim.x : -1;
+    }
+    has_next = v_next >= 0;
+    if (has_next) nxt = make_desc(v_next);
+  }
+  if (dyn && tid == 0) {          // the last workgroup to leave resets the queue for the next launch
+    __threadfence();
+    if (atomicAdd(p.tile_queue + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) atomicExch(p.tile_queue + k, 0);
+    }
   }
   if (p.stamps && tid == 0) {
     unsigned long long* o = p.stamps + 4 * (size_t)blockIdx.x;
@@ -1183,6 +1227,25 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   const int nhs_total = 2 * (int)((p.K + T_BK - 1) / T_BK);
   const bool persist = persist_ok && sizeof(TOut) == 2 && p.split_k == 1 && nhs_total >= 4 && (int)grid.x > num_cus();
   if (persist) grid.x = (unsigned)num_cus();
+  p.tile_queue = nullptr;
+  if (persist) {
+    // MDT_GEMM_DYNAMIC=1: dynamic tile queue instead of the static round-robin walk (in-call A/B on an otherwise idle
+    // chip: static is 1.5 % faster — two more barriers per tile, and raided tiles leave their XCD's L2 — so dynamic
+    // is what ddp.py selects when RCCL kernels share the chip).  64 queue sets are used in turn, each zeroed once
+    // here and put back to zero by the last workgroup of the launch that used it.
+    static int* queues = nullptr;
+    static unsigned turn = 0;
+    const char* de = getenv("MDT_GEMM_DYNAMIC");
+    if (de != nullptr && atoi(de) != 0) {
+      if (!queues) {
+        if (hipMalloc(&queues, 64 * 16 * sizeof(int)) != hipSuccess || hipMemset(queues, 0, 64 * 16 * sizeof(int)) != hipSuccess) {
+          (void)hipGetLastError();
+          queues = nullptr;
+        }
+      }
+      if (queues) p.tile_queue = queues + 16 * (turn++ & 63);
+    }
+  }
   {
     // Tile order.  Row-major (group_n = tiles_n) unless B is too wide for an XCD's 4-MiB L2 and splits evenly in
     // two halves that do fit: then XCDs 0-3 sweep the left half of the columns and XCDs 4-7 the right half, over the
@@ -1315,6 +1378,7 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   p.drop = make_drop((epilogue & MDT_EPI_DROPOUT) ? drop_p : 0.f, drop_seed);
   p.colsum = colsum;
   p.stamps = nullptr;
+  p.tile_queue = nullptr;
   p.group_n = 1 << 30;   // row-major unless launch_pp256 decides otherwise
   if (const char* dg = getenv("MDT_GEMM_DIAG")) p.epilogue |= atoi(dg) << 20;   // 1: skip stores, 2: sc1 stores (direct epilogue only)
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_COLSUM) || (colsum && split_k == 1), "mdt_gemm: MDT_EPI_COLSUM needs a colsum buffer and split_k == 1");

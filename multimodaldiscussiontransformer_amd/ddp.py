@@ -179,12 +179,12 @@ class DataParallel:
         self.bucketer = GradientBucketer(params, flat, bucket_mb << 20, process_group, stream)
         if self.bucketer.world > 1:
             # RCCL's kernels run beside backward and take whole CUs (a ping-pong GEMM workgroup leaves no LDS for a
-            # neighbour).  The persistent GEMM assumes one resident workgroup per CU from start to end: with some
-            # CUs busy elsewhere its statically assigned tiles would wait for a whole pass.  The one-tile-per-
-            # workgroup form degrades in proportion instead, so it is the multi-GPU default (in-call A/B at one
-            # GPU: persistent is 1.7 % faster when it owns the chip).
+            # neighbour).  The persistent GEMM with a STATIC tile walk assumes one resident workgroup per CU from start
+            # to end: with some CUs busy elsewhere its statically assigned tiles would wait for a whole pass.  Its
+            # dynamic tile queue lets a late or time-shared CU simply take fewer tiles (idle chip, in-call A/B: static
+            # +1.5 % over dynamic, dynamic +1.5 % over one tile per workgroup).
             import os
-            os.environ.setdefault("MDT_GEMM_PERSIST", "0")
+            os.environ.setdefault("MDT_GEMM_DYNAMIC", "1")
         ge.grad_ready_hook = self.bucketer.on_params_ready
         self._steps = 0
 

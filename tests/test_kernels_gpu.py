@@ -161,10 +161,13 @@ def test_gemm_bf16_out_big_tiles(ops, M, N, K, tb, monkeypatch):
     ad, bd = dev(a), dev(b)
     ref = ad.float() @ (bd.float() if tb else bd.float().t())
     tol = dict(atol=0.06, rtol=1.5e-2)
-    for persist in ("1", "0"):
+    for persist, dynamic in (("1", "0"), ("1", "1"), ("0", "0")):     # static walk, dynamic tile queue, one tile per workgroup
         monkeypatch.setenv("MDT_GEMM_PERSIST", persist)
-        out = ops.gemm(ad, bd, trans_b=bool(tb))
-        torch.testing.assert_close(out.float(), ref, **tol)
+        monkeypatch.setenv("MDT_GEMM_DYNAMIC", dynamic)
+        for _ in range(2):                                            # twice: the queue must come back zeroed
+            out = ops.gemm(ad, bd, trans_b=bool(tb))
+            torch.testing.assert_close(out.float(), ref, **tol)
+    monkeypatch.setenv("MDT_GEMM_DYNAMIC", "0")
     cs = torch.zeros(N, dtype=torch.float32).cuda()
     out = ops.gemm(ad, bd, trans_b=bool(tb), bias=dev(bias), residual=dev(res), colsum=cs)
     full = ref + dev(bias).float() + dev(res).float()
