@@ -22,9 +22,9 @@ namespace mdt {
 constexpr int V2_LD = 72;  // LDS image row stride in elements (144 B)
 
 template <int HD>
-__device__ __forceinline__ void v2_stage(bf16_t* img, const bf16_t* g, int64_t g_ld, int S, int rows_pad, int tid) {
+__device__ __forceinline__ void v2_stage(bf16_t* img, const bf16_t* g, int64_t g_ld, int S, int rows_pad, int tid, int nthr = 256) {
   constexpr int CH = HD / 8;
-  for (int e = tid; e < rows_pad * CH; e += 256) {
+  for (int e = tid; e < rows_pad * CH; e += nthr) {
     const int r = e / CH, c = e - r * CH;
     bf16x8 v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     if (r < S) v = *(const bf16x8*)(g + r * g_ld + c * 8);
@@ -71,8 +71,8 @@ __device__ __forceinline__ float col_sum(float v) {
 // 16 output values of a lane are scaled by 1 / sum (and 1 / (1 - p)) at the end; dropout decides two
 // neighbouring keys per mixer word.  Kernels without structural bias take no per-pair bias at all — a plain
 // dense bias is served by attention.hip (see the dispatch there).
-template <int HD, int NT, bool STRUCT, bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_v2_kernel(AttnParams P) {
+template <int HD, int NT, bool STRUCT, bool DROP, int NW>     // NW waves: 4, or 8 for long sequences (two workgroups per CU by LDS)
+__global__ __launch_bounds__(NW * 64) void attn_fwd_v2_kernel(AttnParams P) {
   constexpr int ND = HD / 16, NP = (NT + 1) / 2, S_PAD = NP * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mdt_attn_fwd_args& a = P.f;
@@ -93,29 +93,29 @@ __global__ __launch_bounds__(256) void attn_fwd_v2_kernel(AttnParams P) {
   const int ntk = (S + 15) >> 4;
   // The Q fragments of every query tile this wave will visit are requested BEFORE K / V are staged, so their global
   // latency overlaps the staging (measured: the waves of this kernel sat in s_waitcnt / s_barrier 68 % of their
-  // cycles, mostly on the per-tile Q loads).  A wave owns tiles wave, wave + 4, ... : at most MAXT of them.
-  constexpr int MAXT = (NT + 3) / 4;
+  // cycles, mostly on the per-tile Q loads).  A wave owns tiles wave, wave + NW, ... : at most MAXT of them.
+  constexpr int MAXT = (NT + NW - 1) / NW;
   int n_qt = (S + 15) >> 4;
   if (a.q_limit > 0 && ((a.q_limit + 15) >> 4) < n_qt) n_qt = (a.q_limit + 15) >> 4;   // only these query tiles are needed
   bf16x8 fq_all[MAXT][HD / 32];
 #pragma unroll
   for (int k = 0; k < MAXT; ++k) {
-    const int qt_k = wave + 4 * k;
+    const int qt_k = wave + NW * k;
     if (qt_k < n_qt) {
 #pragma unroll
       for (int ks = 0; ks < HD / 32; ++ks) fq_all[k][ks] = v2_frag_glb(qkv, tld, S, qt_k * 16, ks * 32, lane);
     }
   }
-  v2_stage<HD>(imgK, qkv + D, tld, S, S_PAD, tid);
-  v2_stage<HD>(imgV, qkv + 2 * D, tld, S, S_PAD, tid);
-  for (int i = tid; i < S_PAD; i += 256) s_kb[i] = key_only_bias<bf16_t>(bc, i);
+  v2_stage<HD>(imgK, qkv + D, tld, S, S_PAD, tid, NW * 64);
+  v2_stage<HD>(imgV, qkv + 2 * D, tld, S, S_PAD, tid, NW * 64);
+  for (int i = tid; i < S_PAD; i += NW * 64) s_kb[i] = key_only_bias<bf16_t>(bc, i);
   __syncthreads();
   const int drop_bh = seq * a.H + h;   // counters: attention_common.hpp
   const float scale2 = a.scale * LOG2E;
   const int g = lane >> 4, c = lane & 15;
 #pragma unroll
   for (int k = 0; k < MAXT; ++k) {
-    const int qt = wave + 4 * k;
+    const int qt = wave + NW * k;
     if (qt >= n_qt) break;
     const int q0 = qt * 16;
     const int q = q0 + c;
@@ -417,6 +417,7 @@ __device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mdt_attn_fwd_args& a = P.f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = blockDim.x, nw = nthr >> 6;      // 4 waves, or 8 for long sequences in the 128-register build
   const int h = blockIdx.x, seq = blockIdx.y;
   const int SL = a.S, D = a.H * HD;                      // SL: lse / dropout-counter geometry
   const int S = a.seq_offsets ? a.seq_offsets[seq + 1] - a.seq_offsets[seq] : a.S;   // this sequence's length
@@ -447,13 +448,13 @@ __device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad)
       fo_n[ks] = v2_frag_glb(dout, dld, S, wave * 16, ks * 32, lane);
     }
   }
-  v2_stage<HD>(img0, qkv + D, tld, S, s_live, tid);      // K
-  v2_stage<HD>(img1, qkv + 2 * D, tld, S, s_live, tid);  // V
+  v2_stage<HD>(img0, qkv + D, tld, S, s_live, tid, nthr);      // K
+  v2_stage<HD>(img1, qkv + 2 * D, tld, S, s_live, tid, nthr);  // V
   // s_lse holds lse * log2(e) (+inf for rows without a finite lse, so every p of such a row is exp2(-inf) = 0);
   // s_delta holds delta * (1 - p_drop): the 1 / (1 - p_drop) factor of the dropout mask is folded out of
   // dS and dV and applied once to the outputs.
   const float ik = DROP ? P.drop.inv_keep : 1.0f, rik = 1.0f / ik;
-  for (int i = tid; i < s_live; i += 256) {
+  for (int i = tid; i < s_live; i += nthr) {
     s_kb[i] = key_only_bias<bf16_t>(bc, i);
     float l = -INFINITY, de = 0.f;
     // rows beyond q_limit were not computed by the forward pass (out / lse unspecified) and carry no gradient:
@@ -471,7 +472,7 @@ __device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad)
     s_lse[i] = (l == -INFINITY) ? INFINITY : l * LOG2E;
     s_delta[i] = de * rik;
   }
-  for (int i = tid; i < nhist; i += 256) s_hist[i] = 0.f;
+  for (int i = tid; i < nhist; i += nthr) s_hist[i] = 0.f;
   __syncthreads();
   const int drop_bh = seq * a.H + h;   // counters: attention_common.hpp
   const uint32_t s2h = (uint32_t)((SL + 1) >> 1);
@@ -485,7 +486,7 @@ __device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad)
   const int n_chunk_q = (a.q_limit > 0 && ((a.q_limit + 63) >> 6) < n_chunk) ? (a.q_limit + 63) >> 6 : n_chunk;
 
   // ------------------------------------------------------------------ pass A (queries on lanes)
-  for (int qt = wave; qt < n_tq; qt += 4) {
+  for (int qt = wave; qt < n_tq; qt += nw) {
     const int q0 = qt * 16;
     const int q = q0 + c;
     const bool qok = q < S;
@@ -496,11 +497,11 @@ __device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad)
       if constexpr (PF) { fq[ks] = fq_n[ks]; fo[ks] = fo_n[ks]; }
       else { fq[ks] = v2_frag_glb(qkv, tld, S, q0, ks * 32, lane); fo[ks] = v2_frag_glb(dout, dld, S, q0, ks * 32, lane); }
     }
-    if (PF && qt + 4 < n_tq) {
+    if (PF && qt + nw < n_tq) {
 #pragma unroll
       for (int ks = 0; ks < HD / 32; ++ks) {
-        fq_n[ks] = v2_frag_glb(qkv, tld, S, q0 + 64, ks * 32, lane);
-        fo_n[ks] = v2_frag_glb(dout, dld, S, q0 + 64, ks * 32, lane);
+        fq_n[ks] = v2_frag_glb(qkv, tld, S, q0 + 16 * nw, ks * 32, lane);
+        fo_n[ks] = v2_frag_glb(dout, dld, S, q0 + 16 * nw, ks * 32, lane);
       }
     }
     const float l2 = s_lse[qc], del = s_delta[qc];
@@ -582,11 +583,11 @@ __device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad)
     }
   }
   __syncthreads();   // K / V images are free
-  v2_stage<HD>(img0, qkv, tld, S, s_live, tid);    // Q
-  v2_stage<HD>(img1, dout, dld, S, s_live, tid);   // dO
+  v2_stage<HD>(img0, qkv, tld, S, s_live, tid, nthr);    // Q
+  v2_stage<HD>(img1, dout, dld, S, s_live, tid, nthr);   // dO
   if constexpr (STRUCT) {
     if (P.d_sp_table) {
-      for (int i = tid; i <= a.num_spatial; i += 256) {
+      for (int i = tid; i <= a.num_spatial; i += nthr) {
         const float v = s_hist[i];
         if (v != 0.f) {
           if (i < a.num_spatial) atomicAdd(P.d_sp_table + (int64_t)i * a.H + h, v);
@@ -602,7 +603,7 @@ __device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad)
   // computes two of them and they trade through one DPP quad swap each.
   const int odd = c & 1;
   const uint32_t base_rp = (uint32_t)(drop_bh * SL) * s2h;
-  for (int kt = wave; kt < n_t; kt += 4) {
+  for (int kt = wave; kt < n_t; kt += nw) {
     const int key0 = kt * 16;
     const int key = key0 + c;
     const bool kok = key < S;
@@ -613,11 +614,11 @@ __device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad)
       if constexpr (PF) { fk[ks] = fk_n[ks]; fv[ks] = fv_n[ks]; }
       else { fk[ks] = v2_frag_glb(qkv + D, tld, S, key0, ks * 32, lane); fv[ks] = v2_frag_glb(qkv + 2 * D, tld, S, key0, ks * 32, lane); }
     }
-    if (PF && kt + 4 < n_t) {
+    if (PF && kt + nw < n_t) {
 #pragma unroll
       for (int ks = 0; ks < HD / 32; ++ks) {
-        fk_n[ks] = v2_frag_glb(qkv + D, tld, S, key0 + 64, ks * 32, lane);
-        fv_n[ks] = v2_frag_glb(qkv + 2 * D, tld, S, key0 + 64, ks * 32, lane);
+        fk_n[ks] = v2_frag_glb(qkv + D, tld, S, key0 + 16 * nw, ks * 32, lane);
+        fv_n[ks] = v2_frag_glb(qkv + 2 * D, tld, S, key0 + 16 * nw, ks * 32, lane);
       }
     }
     const uint32_t kh = base_rp + (uint32_t)(key >> 1);
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v3_kernel(AttnParams P, int s_pa
 // Short sequences (S <= 128: 38 KB of LDS, four workgroups fit a CU): the same body held to 128 registers (a handful
 // spill) so that four waves per SIMD are resident — the ragged BERT sequences are latency-bound, not register-bound.
 template <int HD, bool DROP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_v3_occ4_kernel(AttnParams P, int s_pad) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_v3_occ4_kernel(AttnParams P, int s_pad) {
   attn_bwd_v3_body<HD, false, DROP, false>(P, s_pad);   // the 128-register build has no room for the look-ahead
 }
 
@@ -719,6 +720,12 @@ static int launch_v3(hipStream_t st, const AttnParams& p) {
     if (s_pad <= 128 && getenv("MDT_ATTN_NO_OCC4") == nullptr) {
       hipLaunchKernelGGL((attn_bwd_v3_occ4_kernel<64, DROP>), dim3(p.f.H, p.f.nseq), 256, lds, st, p, s_pad);
       return check_launch("attention_bwd_v3_occ4");
+    }
+    // long sequences (ViT: 13 tiles): LDS allows two workgroups per CU; 8 waves each in the 128-register build
+    // = 4 waves per SIMD instead of 2
+    if (s_pad > 128 && getenv("MDT_ATTN_NO_W8") == nullptr) {      // in-call A/B at the ViT shape: +0.7 % on the step
+      hipLaunchKernelGGL((attn_bwd_v3_occ4_kernel<64, DROP>), dim3(p.f.H, p.f.nseq), 512, lds, st, p, s_pad);
+      return check_launch("attention_bwd_v3_w8");
     }
   }
   hipLaunchKernelGGL(kern, dim3(p.f.H, p.f.nseq), 256, lds, st, p, s_pad);
@@ -743,9 +750,10 @@ static int launch_v2(hipStream_t st, const AttnParams& p) {
     set_error("attention_v2: backward supports S <= 112 (got %d)", p.f.S);
     return MDT_ERR_UNSUPPORTED;
   } else {
+    constexpr int NWF = (NT >= 13 && !STRUCT) ? 8 : 4;     // forward: 8 waves for the long (ViT) rows, 4 waves per SIMD
     const void* kern;
     if constexpr (BWD) kern = (const void*)attn_bwd_v2_kernel<64, NT, STRUCT, DROP>;
-    else kern = (const void*)attn_fwd_v2_kernel<64, NT, STRUCT, DROP>;
+    else kern = (const void*)attn_fwd_v2_kernel<64, NT, STRUCT, DROP, NWF>;
     if (lds > 64 * 1024) {
       if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
@@ -754,7 +762,7 @@ static int launch_v2(hipStream_t st, const AttnParams& p) {
       }
     }
     if constexpr (BWD) hipLaunchKernelGGL((attn_bwd_v2_kernel<64, NT, STRUCT, DROP>), dim3(p.f.H, p.f.nseq), 256, lds, st, p);
-    else hipLaunchKernelGGL((attn_fwd_v2_kernel<64, NT, STRUCT, DROP>), dim3(p.f.H, p.f.nseq), 256, lds, st, p);
+    else hipLaunchKernelGGL((attn_fwd_v2_kernel<64, NT, STRUCT, DROP, NWF>), dim3(p.f.H, p.f.nseq), NWF * 64, lds, st, p);
     return check_launch(BWD ? "attention_bwd_v2" : "attention_fwd_v2");
   }
 }
