@@ -499,3 +499,35 @@ def test_attention_query_limit(ops, dtype, S, H, qlim):
     torch.testing.assert_close(o_lim.view(nseq, S, D)[:, :qlim].float(), o_full.view(nseq, S, D)[:, :qlim].float(), **tol)
     torch.testing.assert_close(l_lim[:, :, :qlim], l_full[:, :, :qlim], atol=1e-4, rtol=1e-5)
     torch.testing.assert_close(g_lim.float(), g_full.float(), **tol)
+
+
+# ----------------------------------------------------------------------------- error behaviour of the C ABI
+def test_abi_rejects_bad_arguments_loudly(ops):
+    """Every entry point returns a negative status (raised as MdtError with the library's message) instead of
+    launching something undefined: bad epilogue combinations, unsupported shapes, inconsistent ragged arguments."""
+    from multimodaldiscussiontransformer_amd._lib import MdtError
+    bf = torch.bfloat16
+    a, b = dev(rnd(64, 64, seed=1).to(bf)), dev(rnd(64, 64, seed=2).to(bf))
+    with pytest.raises(MdtError, match="split_k"):
+        ops.gemm(a, b, split_k=4)                                   # split-K without the atomic epilogue
+    with pytest.raises(MdtError, match="MULAUX|DGELU"):
+        ops.gemm(a, b, epilogue=ops.EPI_MULAUX)                     # multiply-by-aux without aux
+    with pytest.raises(MdtError, match="AUX_GRAD"):
+        ops.gemm(a, b, aux=torch.empty_like(a), epilogue=ops.EPI_AUX_GRAD)   # derivative of nothing
+    with pytest.raises(MdtError, match="dropout"):
+        ops.gemm(a, b, epilogue=ops.EPI_DROPOUT, drop_p=1.0)
+    H, hd = 2, 64
+    with pytest.raises(MdtError, match="272|exceeds|limit"):
+        S = 300
+        ops.attention_fwd(dev(rnd(S, 3 * H * hd, seed=3).to(bf)), 1, S, H)   # longer than one attention call supports
+    S = 40
+    qkv = dev(rnd(2 * S, 3 * H * hd, seed=4).to(bf))
+    off = dev(torch.tensor([0, S, 2 * S], dtype=torch.int32))
+    km = dev(torch.ones(2, S, dtype=torch.uint8))
+    with pytest.raises(MdtError, match="ragged"):
+        ops.attention_fwd(qkv, 2, S, H, seq_offsets=off, key_mask=km)        # ragged sequences take no masks
+    with pytest.raises(MdtError, match="head_dim"):
+        ops.attention_fwd(dev(rnd(S, 3 * 2 * 32, seed=5).to(bf)), 1, S, 2)  # bf16 path: head_dim 64 only
+    # the library stays usable after errors
+    out = ops.gemm(a, b)
+    torch.testing.assert_close(out.float(), a.float() @ b.float().t(), atol=0.1, rtol=2e-2)
