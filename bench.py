@@ -223,35 +223,65 @@ def selfcheck():
     torch.cuda.synchronize()
 
 
-def selfcheck_model(model, pb, build_fp32):
-    """End-to-end guard at the bench's own batch: bf16 logits of the tape that is about to be timed (ragged text,
-    big-tile persistent GEMMs, v2 / v3 attention) against (a) the same weights run in fp32 through the parity path
-    (generic fp32 MFMA GEMMs, fp32 attention — the path the golden-vector tests pin to the reference) and (b) the
-    bf16 tape in the reference's padded text layout.  Eval mode (no dropout), forward only."""
+def selfcheck_model(model, pb, build_fp32, crit=None):
+    """End-to-end guard at the bench's own batch, eval mode (no dropout):
+    (a) bf16 logits of the tape that is about to be timed (ragged text, pruned last fusion layer, big-tile persistent
+        GEMMs, v2 / v3 attention) against the same weights run in fp32 through the parity path (generic fp32 MFMA GEMMs,
+        fp32 attention — the path the golden-vector tests pin to the reference);
+    (b) the same logits against the bf16 tape in the reference's layout (every padded token, every row of every layer);
+    (c) with ``crit``: the parameter gradients of one backward pass in the two layouts against each other."""
     ge = model.encoder.graph_encoder
     was_training = model.training
     model.eval()
+    keep = (ge.ragged_tokens, ge.prune_last_layer)
+    sample = {"nsamples": pb.B, "net_input": {"batched_data": pb.batched_data}}
+
+    def grads():
+        model.main_grad_flat.zero_()
+        loss, _, _ = crit(model, sample)
+        loss.backward()
+        picks = {}
+        for n, p_ in model.named_parameters():
+            if hasattr(p_, "main_grad") and p_.numel() >= 1 << 16 and any(k in n for k in ("layer.0.", "layer.11.", "layers.0.", "patch_embeddings", "word_embeddings")):
+                picks[n] = p_.main_grad.detach().clone()
+        return float(loss.detach()), picks
+
     with torch.no_grad():
         lg, glob = model(pb.batched_data)
-        keep = ge.ragged_tokens
-        ge.ragged_tokens = not keep
+    res_fast = grads() if crit is not None else None
+    ge.ragged_tokens, ge.prune_last_layer = False, False
+    with torch.no_grad():
         lg_other, glob_other = model(pb.batched_data)
-        ge.ragged_tokens = keep
+    res_ref = grads() if crit is not None else None
+    ge.ragged_tokens, ge.prune_last_layer = keep
+    with torch.no_grad():
         m32 = build_fp32()
         m32.load_state_dict(model.state_dict())          # same (bf16-rounded) weights, fp32 arithmetic
         m32.eval()
         lg32, glob32 = m32(pb.batched_data)
         del m32
     model.train(was_training)
+    model.main_grad_flat.zero_()
     d_layout = float((lg.float() - lg_other.float()).abs().max())
     d_fp32 = float((lg.float() - lg32).abs().max())
     scale = max(1.0, float(lg32.abs().max()))
-    if not (d_layout <= 0.05 * scale and d_fp32 <= 0.08 * scale):
-        raise SystemExit(f"bench self-check failed: bf16 logits differ from the padded layout by {d_layout:.3g} and from the "
-                         f"fp32 parity path by {d_fp32:.3g} (|logits| up to {scale:.3g})")
+    sig = lambda x: float(f"{x:.3g}")
+    out = dict(logits_vs_fp32_parity_path=sig(d_fp32), logits_fast_vs_reference_layout=sig(d_layout), logits_absmax=sig(float(lg32.abs().max())))
+    ok = d_layout <= 0.05 * scale and d_fp32 <= 0.08 * scale
+    if crit is not None:
+        worst = 0.0
+        for n, g in res_fast[1].items():
+            r = res_ref[1][n]
+            rel = float((g - r).norm() / (r.norm() + 1e-20))
+            worst = max(worst, rel)
+        out.update(grad_rel_l2_fast_vs_reference_layout=sig(worst), grad_tensors_compared=len(res_fast[1]),
+                   loss_fast_vs_reference_layout=sig(abs(res_fast[0] - res_ref[0])), loss=sig(res_ref[0]))
+        ok = ok and worst <= 0.05 and abs(res_fast[0] - res_ref[0]) <= 0.05
+    if not ok:
+        raise SystemExit(f"bench self-check failed: {out}")
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
-    return dict(logits_vs_fp32_parity_path=round(d_fp32, 4), logits_ragged_vs_padded=round(d_layout, 4), logits_absmax=round(scale, 3))
+    return out
 
 
 def main():
@@ -328,7 +358,7 @@ def main():
     model_check = None
     if args.dtype == "bf16" and not args.no_selfcheck:
         model_check = selfcheck_model(model, batches[0],
-                                      lambda: GraphormerModel.build_model(base_args(args), task=None).cuda().float())
+                                      lambda: GraphormerModel.build_model(base_args(args), task=None).cuda().float(), crit)
     comments_per_step = batches[0].M
     scal = torch.zeros(6, dtype=torch.float32, device="cuda")
 
