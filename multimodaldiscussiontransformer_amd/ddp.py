@@ -33,6 +33,7 @@ class GradientBucketer:
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.pg = process_group
         self.comm_stream = comm_stream
+        self.compute_streams: List["torch.cuda.Stream"] = []    # beside the current one (two-stream tapes: engine.side_stream)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # MDT_DDP_FORCE=1: issue the collectives even at world size 1 (exercises the RCCL / side-stream path
         # on a single-GPU box; an all-reduce over one rank is the identity)
@@ -129,9 +130,7 @@ class GradientBucketer:
             return
         chunk = self.flat[a:b]
         if self.comm_stream is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.comm_stream.wait_event(ev)
+            self._comm_waits_for_compute()
             with torch.cuda.stream(self.comm_stream):
                 self.handles.append(dist.all_reduce(chunk, group=self.pg, async_op=True))
         else:
@@ -159,10 +158,15 @@ class GradientBucketer:
             self.flat.div_(scalars[sample_size_index].clamp(min=1.0))
         self.reset()
 
+    def _comm_waits_for_compute(self):
+        """The gradients of a bucket were written by kernels on the current stream and, with a two-stream tape, on the
+        other branch's stream: the collective waits for both."""
+        cur = torch.cuda.current_stream()
+        for s in [cur] + [s for s in self.compute_streams if s != cur]:
+            self.comm_stream.wait_stream(s)
+
     def _scalar_reduce(self, scalars):
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self.comm_stream.wait_event(ev)
+        self._comm_waits_for_compute()
         with torch.cuda.stream(self.comm_stream):
             return dist.all_reduce(scalars, group=self.pg, async_op=True)
 
@@ -185,6 +189,9 @@ class DataParallel:
             # +1.5 % over dynamic, dynamic +1.5 % over one tile per workgroup).
             import os
             os.environ.setdefault("MDT_GEMM_DYNAMIC", "1")
+        if flat.is_cuda and getattr(ge, "two_streams", False):
+            from . import engine
+            self.bucketer.compute_streams = [torch.cuda.current_stream(), engine.side_stream(flat.device)]
         ge.grad_ready_hook = self.bucketer.on_params_ready
         self._steps = 0
 

@@ -16,6 +16,8 @@ temporaries that are handed back to autograd as ordinary ``.grad``s.
 """
 from __future__ import annotations
 
+import contextlib
+import threading
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
 
@@ -24,14 +26,32 @@ import torch
 from . import ops
 
 
+class _StreamState(threading.local):
+    """Which branch the calling thread is enqueuing for (autograd runs a tape's backward on its own thread)."""
+    side_active = False
+
+
+_SS = _StreamState()
+_SIDE_STREAMS = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """The second HIP stream of ``device`` (one per process and device): the image branch of a two-stream tape."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
+
+
 class Var:
     """An activation on the tape: data + lazily created gradient buffer."""
-    __slots__ = ("data", "grad", "needs_grad")
+    __slots__ = ("data", "grad", "needs_grad", "side")
 
     def __init__(self, data: torch.Tensor, needs_grad: bool = True):
         self.data = data
         self.grad: Optional[torch.Tensor] = None
         self.needs_grad = needs_grad
+        self.side = _SS.side_active            # produced (and consumed) by the image branch of a two-stream tape
 
     @property
     def rows(self):
@@ -47,6 +67,67 @@ class Tape:
         self.on_params_ready = on_params_ready     # DDP hook: called with the params an op just finished
         self._seed_base = None
         self._seed_ctr = 0
+        self.side: Optional[torch.cuda.Stream] = None
+        self._main: Optional[torch.cuda.Stream] = None
+
+    # -- two HIP streams ------------------------------------------------------------------
+    # The text and image branches of mDT are independent between bottleneck exchanges (the 6 + 6 pre-fusion layers,
+    # and the two blocks of every fusion layer).  A two-stream tape enqueues the image branch on a second stream, so
+    # the last partially filled wave of one branch's GEMM tiles and its small kernels run beside the other branch's
+    # work.  The discipline that keeps this race-free:
+    #   * ``fork()``  — side waits for everything main has enqueued; ``join()`` — main waits for side.  In backward
+    #     the tape is walked in reverse, so a fork acts as a join and vice versa (both are recorded on the tape).
+    #   * only ops inside ``on_side()`` run on the side stream, and they touch nothing but image-branch tensors
+    #     (allocated there, by the stream-aware caching allocator), parameters, parameter gradients and index
+    #     vectors (all persistent).  Exchange ops run on main strictly between a join and the next fork.
+    #   * the one tensor class that crosses the other way — a gradient buffer that a main-stream adjoint creates for
+    #     an image-branch activation — is marked with ``record_stream`` so the allocator does not recycle it while
+    #     the side stream still reads it.
+    def enable_side(self, device):
+        if self.side is None:
+            self.side = side_stream(device)
+
+    def fork(self):
+        if self.side is None:
+            return
+        self.side.wait_stream(torch.cuda.current_stream())
+        self.record(lambda: torch.cuda.current_stream().wait_stream(self.side))
+
+    def join(self):
+        if self.side is None:
+            return
+        torch.cuda.current_stream().wait_stream(self.side)
+        self.record(lambda: self.side.wait_stream(torch.cuda.current_stream()))
+
+    def _enter_side(self):
+        self._main = torch.cuda.current_stream()
+        torch.cuda.set_stream(self.side)
+        _SS.side_active = True
+
+    def _leave_side(self):
+        if _SS.side_active:
+            torch.cuda.set_stream(self._main)
+            _SS.side_active = False
+
+    @contextlib.contextmanager
+    def on_side(self):
+        """Ops issued inside run on the side stream, forward and backward (no-op on a single-stream tape)."""
+        if self.side is None:
+            yield
+            return
+        self.record(self._leave_side)             # backward reaches the region's first op last
+        self._enter_side()
+        try:
+            yield
+        finally:
+            self._leave_side()
+            self.record(self._enter_side)
+
+    def _crossing(self, v: "Var", t: torch.Tensor):
+        """``t`` was just allocated on the current stream as a gradient of ``v``: tell the allocator when the other
+        branch is the one that will read it."""
+        if self.side is not None and v.side != _SS.side_active:
+            t.record_stream(self.side if v.side else self._main)
 
     def next_seed(self) -> int:
         """A fresh 63-bit dropout-site seed (CPU generator: follows torch.manual_seed, no device sync)."""
@@ -79,6 +160,7 @@ class Tape:
         """Gradient buffer of ``v`` for sparse (row-wise) accumulation; zero-created on first use."""
         if v.grad is None:
             v.grad = torch.zeros_like(v.data)
+            self._crossing(v, v.grad)
         return v.grad
 
     def add_grad(self, v: Var, g: torch.Tensor):
@@ -87,13 +169,23 @@ class Tape:
             return
         if v.grad is None:
             v.grad = g
+            self._crossing(v, g)
         else:
             ops.row_axpby(v.grad, v.grad.shape[0], a=g, accumulate=True)
 
     def backward(self):
-        while self.ops:
-            self.ops.pop()()
+        try:
+            while self.ops:
+                self.ops.pop()()
+        finally:
+            self._leave_side()
         self.ops = []
+        self.sync_streams()
+
+    def sync_streams(self):
+        """End of a pass: whatever follows on the main stream sees the side stream's work."""
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
 
 # ------------------------------------------------------------------------------------------
@@ -691,7 +783,11 @@ class TapeFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         tape = Tape(use_main_grad=use_main_grad, on_params_ready=hook, inference=inference)
         ins = [Var(t, needs_grad=t.requires_grad) for t in tensors[:n_in]]
-        outs = run(tape, *ins)
+        try:
+            outs = run(tape, *ins)
+        finally:
+            tape._leave_side()
+        tape.sync_streams()
         ctx.tape, ctx.ins, ctx.outs = tape, ins, outs
         ctx.params = tensors[n_in:]
         ctx.n_in = n_in

@@ -54,14 +54,19 @@ class GraphFusionLayer(nn.Module):
         if vit is not None:
             E.rows_mix(tape, vit, text, I * nb, alpha=1.0, beta=0.0, d_idx=vit_bn_rows, s_idx=img_text_bn_rows)
         # pruned layer: the kept rows (bottleneck 0, [CLS]) are among the first nb + 1 rows of a comment, row 0 of an image
+        # the two blocks are independent: on a two-stream tape the image block runs beside the text block
+        vit_out = None
+        if vit is not None:
+            tape.fork()
+            with tape.on_side():
+                spec_v = E.AttnSpec(nseq=I, S=Sv, H=ve.heads, q_limit=0 if prune is None else 1)
+                vit_out = E.transformer_block(tape, vit, ve.block_params(), spec_v, pre_ln=True, eps=ve.eps, **ve.drop_kwargs(),
+                                              keep_rows=None if prune is None else prune["vit_keep"])
         spec_t = E.AttnSpec(nseq=M, H=be.heads, q_limit=0 if prune is None else nb + 1, **text_spec)
         text_out = E.transformer_block(tape, text, be.block_params(), spec_t, pre_ln=False, eps=be.eps, **be.drop_kwargs(),
                                        keep_rows=None if prune is None else prune["text_keep"])
-        vit_out = None
         if vit is not None:
-            spec_v = E.AttnSpec(nseq=I, S=Sv, H=ve.heads, q_limit=0 if prune is None else 1)
-            vit_out = E.transformer_block(tape, vit, ve.block_params(), spec_v, pre_ln=True, eps=ve.eps, **ve.drop_kwargs(),
-                                          keep_rows=None if prune is None else prune["vit_keep"])
+            tape.join()
             if prune is None:
                 E.rows_mix(tape, text_out, vit_out, I * nb, alpha=0.5, beta=0.5, d_idx=img_text_bn_rows, s_idx=vit_bn_rows)
             else:   # only bottleneck token 0 is read after the last fusion layer

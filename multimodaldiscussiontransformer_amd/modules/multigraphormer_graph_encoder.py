@@ -123,6 +123,9 @@ class MultiGraphormerGraphEncoder(nn.Module):
         # logits path only (GraphormerModel.forward): the last fusion layer computes just the rows that are read
         # afterwards; MDT_FULL_LAST_LAYER=1 or ``prune_last_layer = False`` computes every row as the reference does
         self.prune_last_layer = os.environ.get("MDT_FULL_LAST_LAYER", "0") != "1"
+        # image branch on a second HIP stream beside the text branch (engine.Tape: fork / join / on_side);
+        # MDT_TWO_STREAMS=0 or ``two_streams = False`` enqueues everything on one stream
+        self.two_streams = os.environ.get("MDT_TWO_STREAMS", "1") != "0"
 
         def set_grad(m, flag):
             if m is not None:
@@ -238,6 +241,24 @@ class MultiGraphormerGraphEncoder(nn.Module):
         Sv, P = ix["Sv"], ix["P"]
         M, I, B, T = pb.M, pb.I, pb.B, pb.T
         tm, vm = self.text_model, self.vit_model
+        if self.two_streams and I > 0:
+            tape.enable_side(pb.ids.device)
+        # the 6 + 6 pre-fusion layers of the two modalities are independent: image branch first (on the side stream of
+        # a two-stream tape), text branch beside it
+        vit = None
+        if I > 0:
+            tape.fork()
+            with tape.on_side():
+                ve = vm.embeddings
+                v = E.vit_embeddings(tape, pb.images, ve.patch_embeddings.projection.weight, ve.patch_embeddings.projection.bias,
+                                     ve.cls_token, ve.position_embeddings, vm.patch)
+                v = E.dropout(tape, v, p_emb)
+                specv = E.AttnSpec(nseq=I, S=P, H=vm.heads)
+                for layer in vm.encoder.layer:
+                    v = E.transformer_block(tape, v, layer.block_params(), specv, pre_ln=True, eps=vm.eps,
+                                            **layer.drop_kwargs())
+                v = E.layernorm(tape, v, vm.layernorm.weight, vm.layernorm.bias, vm.eps)      # quirk 5: final LN mid-network
+                vit = E.expand_sequences(tape, v, I, P, nb, None)
         e = tm.embeddings
         if ix["ragged"]:
             rt = get_ragged(pb)
@@ -251,18 +272,8 @@ class MultiGraphormerGraphEncoder(nn.Module):
         for layer in tm.encoder.layer:
             text = E.transformer_block(tape, text, layer.block_params(), spec0, pre_ln=False, eps=tm.eps,
                                        **layer.drop_kwargs())
-        vit = None
         if I > 0:
-            ve = vm.embeddings
-            v = E.vit_embeddings(tape, pb.images, ve.patch_embeddings.projection.weight, ve.patch_embeddings.projection.bias,
-                                 ve.cls_token, ve.position_embeddings, vm.patch)
-            v = E.dropout(tape, v, p_emb)
-            specv = E.AttnSpec(nseq=I, S=P, H=vm.heads)
-            for layer in vm.encoder.layer:
-                v = E.transformer_block(tape, v, layer.block_params(), specv, pre_ln=True, eps=vm.eps,
-                                        **layer.drop_kwargs())
-            v = E.layernorm(tape, v, vm.layernorm.weight, vm.layernorm.bias, vm.eps)      # quirk 5: final LN mid-network
-            vit = E.expand_sequences(tape, v, I, P, nb, None)
+            tape.join()
         text = E.expand_rows(tape, text, ix["rows_fus"], ix["pre2fus"], ix["bn_rows_all"], nb, self.bottle_neck.weight)
         fargs = (M, ix["spec_fus"], I, Sv, ix["img_text_bn_rows"], ix["vit_bn_rows"])
         text, vit = self.fusion_layers[0]._fwd(tape, text, vit, *fargs)

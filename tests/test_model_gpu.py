@@ -305,6 +305,50 @@ def test_pruned_last_fusion_layer_equals_full_fp32(kind):
         torch.testing.assert_close(g1[n], g0[n], atol=2e-5 * max(1.0, float(g0[n].abs().max())), rtol=1e-4, msg=n)
 
 
+@pytest.mark.parametrize("kind", ["A", "synthetic"])
+def test_two_stream_tape_equals_single_stream(kind):
+    """The image branch enqueued on a second HIP stream (engine.Tape fork / join / on_side) computes what the
+    single-stream tape computes: same dropout sites and seeds, logits bit-identical, gradients equal up to the order
+    of fp32 atomics — over several steps, so that blocks recycled by the caching allocator are exercised too."""
+    from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
+    from multimodaldiscussiontransformer_amd.data.packer import pack_batch
+    from multimodaldiscussiontransformer_amd.models import GraphormerModel
+    from multimodaldiscussiontransformer_amd import synthetic
+    hp = cases.tiny_hparams("A")
+    if kind == "A":
+        trees = cases.tiny_trees(kind, hp)
+    else:
+        trees = synthetic.make_trees(6, 9, seed=77, variable=True, seq_len=16, vocab_size=hp.vocab_size, image_frac=0.5,
+                                     image_size=hp.image_size, min_len=3)
+    res = {}
+    for two in (False, True):
+        model = GraphormerModel.build_model(model_args(hp), task=None)
+        fill_hash_weights(model)
+        model = model.cuda().train()
+        ge = model.encoder.graph_encoder
+        ge.two_streams = two
+        pb = pack_batch(trees, 5)
+        assert pb.I > 0
+        crit = GraphPredictionNodeCrossEntropy(None, positive_weight=1.5, negative_weight=1.0)
+        torch.manual_seed(1234)
+        losses = []
+        for _ in range(3):
+            loss, _, _ = crit(model, {"nsamples": len(trees), "net_input": {"batched_data": pb.batched_data}})
+            loss.backward()
+            losses.append(float(loss.detach()))
+        model.eval()
+        with torch.no_grad():
+            logits, glob = model(pb.batched_data)
+        torch.cuda.synchronize()
+        res[two] = (losses, logits.cpu(), glob.cpu(), {n: p.grad.cpu() for n, p in model.named_parameters() if p.grad is not None})
+    (l0, lg0, gl0, g0), (l1, lg1, gl1, g1) = res[False], res[True]
+    assert l0 == l1
+    assert torch.equal(lg0, lg1) and torch.equal(gl0, gl1)
+    assert set(g0) == set(g1)
+    for n in g0:
+        torch.testing.assert_close(g1[n], g0[n], atol=2e-5 * max(1.0, float(g0[n].abs().max())), rtol=1e-4, msg=n)
+
+
 def test_tree_permutation_and_node_padding_invariance_fp32():
     """SURVEY.md §4 property tests: (a) permuting the trees of a batch permutes the per-comment logits and leaves
     the loss and every parameter gradient unchanged; (b) adding a larger tree to the batch (more node padding N,

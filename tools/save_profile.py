@@ -13,6 +13,9 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = os.path.join(root, "gpurun_out", "")
 dst = os.path.join(root, "profiles", f"{rnd}_{tag}")
 shutil.copy(glob.glob(base + f"{tag}_prof/*/*kernel_stats.csv")[0], dst + "_kernel_stats.csv")
+two = glob.glob(base + f"{tag}_prof2/*/*kernel_stats.csv")
+if two:
+    shutil.copy(two[0], dst + "_kernel_stats_two_streams.csv")
 open(dst + "_bench.json", "w").write(open(base + f"{tag}_bench.log").read().strip().split("\n")[-1] + "\n")
 
 
