@@ -719,12 +719,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
   const int wr = wave >> 2, wc = wave & 3;
   const bool late = wave >= 4;
 
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int bid = blockIdx.x;
+  // Work items = (K slab, tile), slab-major.  Workgroups are dispatched x-fastest and dealt round-robin to the 8 XCDs
+  // by their linear id, so XCD x = id % 8 takes the x-th contiguous run of the work list: with split-K (the weight
+  // gradients: 9-36 tiles per slab, 7-28 slabs) the tiles that share a slab's dY / X panels sit in ONE XCD's L2
+  // instead of being re-fetched through the fabric by all eight (3 x fewer fabric bytes on these launches).
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int nwg = tiles * (int)gridDim.z;
+  const int bid = (int)blockIdx.z * (int)gridDim.x + (int)blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  // Each XCD owns a contiguous run of this order: `group_n` column tiles wide, all the way down the rows, then
-  // the next group (group_n = tiles_n is plain row-major).
+  const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int slab = work / tiles;
+  const int tile = work - slab * tiles;
+  // Within a slab each XCD owns a contiguous run of this order: `group_n` column tiles wide, all the way down the rows,
+  // then the next group (group_n = tiles_n is plain row-major).
   int tm, tn;
   {
     const int G = p.group_n, per_group = p.tiles_m * G;
@@ -742,7 +749,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
     }
   }
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-  const int64_t kbeg = (int64_t)blockIdx.z * p.k_chunk;
+  const int64_t kbeg = (int64_t)slab * p.k_chunk;
   const int64_t kend = (kbeg + p.k_chunk < p.K) ? kbeg + p.k_chunk : p.K;
   const int nk = (int)((kend - kbeg + T_BK - 1) / T_BK);
   const int nhs = 2 * nk;                      // 32-deep steps
