@@ -1,7 +1,7 @@
 set -e
-out=gpurun_out/ab66.log; rm -f $out
-export MDT_DDP_FORCE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0
-for cfg in "MDT_TWO_STREAMS=1" "MDT_TWO_STREAMS=1 GPU_MAX_HW_QUEUES=8" "MDT_TWO_STREAMS=1 GPU_MAX_HW_QUEUES=16" "MDT_TWO_STREAMS=0 GPU_MAX_HW_QUEUES=8" "MDT_TWO_STREAMS=1 MDT_DDP_FORCE=0" "MDT_TWO_STREAMS=1 MDT_DDP_FORCE=0 GPU_MAX_HW_QUEUES=8" "MDT_TWO_STREAMS=1 GPU_MAX_HW_QUEUES=8"; do
-  echo "== $cfg" >> $out
-  env $cfg timeout -k 10 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-selfcheck --no-gemm-timer 2>/dev/null | cut -c1-160 >> $out
-done
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cp gpurun_lib_new.so multimodaldiscussiontransformer_amd/libmdt_hip.so
+timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k gemm > gpurun_out/t69.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_shapes_g1 -- python3 tools/gemm_pmc_shapes.py > gpurun_out/pmc_shapes_g1.log 2>&1
+python tools/gemm_pmc_shapes.py --report gpurun_out/pmc_shapes_g1 > gpurun_out/pmc_g1.log 2>&1
+bash tools/ab_libs.sh
