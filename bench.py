@@ -367,19 +367,28 @@ def main():
     comments_per_step = batches[0].M
     scal = torch.zeros(6, dtype=torch.float32, device="cuda")
 
-    def step(i):
+    host_marks = []
+
+    def step(i, marks=None):
+        mark = (lambda name: marks.append((name, time.perf_counter()))) if marks is not None else (lambda name: None)
+        mark("start")
         pb = batches[i % nbatch]
         dp.zero_grad()
         sample = {"nsamples": pb.B, "net_input": {"batched_data": pb.batched_data}}
+        mark("zero_grad")
         loss, sample_size, log = crit(model, sample)
+        mark("forward+loss")
         loss.backward()
+        mark("backward")
         scal[0] = loss.detach().float()
-        scal[1] = float(sample_size)
+        scal[1].fill_(float(sample_size))        # (scal[1] = <python float> is a synchronous H2D copy: tools/sync_probe.py)
         scal[2:6] = torch.stack([log["ncorrect"], log["num_positive_correct"], log["total_positive"],
                                  log["num_pred_positive"]]).float()
+        mark("scalars")
         dp.finish_backward(scal)
         if opt is not None:
             opt.step()
+        mark("finish")
         return loss
 
     def fence():
@@ -393,9 +402,15 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    t_issue = time.perf_counter() - t0           # host time to ENQUEUE the steps (no sync inside a step)
     fence()
     dt = time.perf_counter() - t0
+    # host time to ENQUEUE one step (no sync inside a step), taken on an idle GPU: inside the back-to-back timed region
+    # the HIP runtime holds the host back once its queues are full, so the loop's host time there just mirrors the GPU's
+    t1 = time.perf_counter()
+    step(args.steps, host_marks)
+    t_issue = time.perf_counter() - t1
+    fence()
+    host_phases = {b[0]: round((b[1] - a[1]) * 1e3, 2) for a, b in zip(host_marks, host_marks[1:])}
     # roofline pass, after the timed region: the same steps on ONE HIP stream with a HIP-event bracket around every GEMM
     # launch.  In the timed region the text and image branches run on two streams and their kernels overlap, so a
     # bracket there times "this kernel plus its wait for compute units held by the other branch", not the kernel.
@@ -434,7 +449,9 @@ def main():
         traffic, traffic_src = None, None
         try:                                       # HBM-side bytes per launch of the GEMM family, from the committed PMC passes
             import glob
-            cand = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+            import re
+            cand = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")),
+                          key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])      # round, version: numeric order
             if cand:
                 traffic = json.load(open(cand[-1]))["gemm_family_bytes_per_launch"]
                 traffic_src = "profiles/" + os.path.basename(cand[-1])
@@ -467,7 +484,7 @@ def main():
             "padded_equivalent_tflops": round(value * 3 * fpc_padded / 1e12, 1),
             "text_layout": "ragged" if ragged else "padded",
             "compute_streams": 2 if model.encoder.graph_encoder.two_streams else 1,     # image branch beside the text branch
-            "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 2),
+            "host_issue_ms_per_step": round(t_issue * 1e3, 2), "host_issue_phases_ms": host_phases,
             "roofline": roofline,
             "selfcheck": "skipped" if (args.no_selfcheck or args.dtype != "bf16") else dict(kernels="passed", **(model_check or {})),
         }

@@ -1238,19 +1238,20 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   if (persist) {
     // MDT_GEMM_DYNAMIC=1: dynamic tile queue instead of the static round-robin walk (in-call A/B on an otherwise idle
     // chip: static is 1.5 % faster — two more barriers per tile, and raided tiles leave their XCD's L2 — so dynamic
-    // is what ddp.py selects when RCCL kernels share the chip).  64 queue sets are used in turn, each zeroed once
-    // here and put back to zero by the last workgroup of the launch that used it.
+    // is what ddp.py selects when RCCL kernels share the chip).  512 queue sets are used in turn, each zeroed once
+    // here and put back to zero by the last workgroup of the launch that used it (launches of the two branch streams
+    // run concurrently, at most a few dozen launches apart in issue order).
     static int* queues = nullptr;
     static unsigned turn = 0;
     const char* de = getenv("MDT_GEMM_DYNAMIC");
     if (de != nullptr && atoi(de) != 0) {
       if (!queues) {
-        if (hipMalloc(&queues, 64 * 16 * sizeof(int)) != hipSuccess || hipMemset(queues, 0, 64 * 16 * sizeof(int)) != hipSuccess) {
+        if (hipMalloc(&queues, 512 * 16 * sizeof(int)) != hipSuccess || hipMemset(queues, 0, 512 * 16 * sizeof(int)) != hipSuccess) {
           (void)hipGetLastError();
           queues = nullptr;
         }
       }
-      if (queues) p.tile_queue = queues + 16 * (turn++ & 63);
+      if (queues) p.tile_queue = queues + 16 * (turn++ & 511);
     }
   }
   {

@@ -81,8 +81,9 @@ class Tape:
     #     (allocated there, by the stream-aware caching allocator), parameters, parameter gradients and index
     #     vectors (all persistent).  Exchange ops run on main strictly between a join and the next fork.
     #   * the one tensor class that crosses the other way — a gradient buffer that a main-stream adjoint creates for
-    #     an image-branch activation — is marked with ``record_stream`` so the allocator does not recycle it while
-    #     the side stream still reads it.
+    #     an image-branch activation — is allocated from the side stream's pool (``grad_buf``), so the allocator
+    #     recycles it in side-stream order; a dense gradient handed over by an op (``add_grad``) falls back to
+    #     ``record_stream``.
     def enable_side(self, device):
         if self.side is None:
             self.side = side_stream(device)
@@ -159,8 +160,18 @@ class Tape:
     def grad_buf(self, v: Var) -> torch.Tensor:
         """Gradient buffer of ``v`` for sparse (row-wise) accumulation; zero-created on first use."""
         if v.grad is None:
-            v.grad = torch.zeros_like(v.data)
-            self._crossing(v, v.grad)
+            if self.side is not None and v.side and not _SS.side_active:
+                # an exchange adjoint (main stream) creates the gradient of an image-branch activation: take the
+                # buffer from the side stream's pool, where its reader will run and where it is freed.  The side
+                # stream is idle here (between a join and the next fork), so waiting for its zero-fill costs nothing;
+                # record_stream instead would park the block behind an event on every free, and a host that runs
+                # steps ahead of the GPU then falls back to hipMalloc
+                with torch.cuda.stream(self.side):
+                    v.grad = torch.zeros_like(v.data)
+                torch.cuda.current_stream().wait_stream(self.side)
+            else:
+                v.grad = torch.zeros_like(v.data)
+                self._crossing(v, v.grad)
         return v.grad
 
     def add_grad(self, v: Var, g: torch.Tensor):

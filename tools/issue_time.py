@@ -26,3 +26,13 @@ torch.cuda.synchronize()
 for _ in range(3):
     t0 = time.perf_counter(); step(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f"enqueue {1e3*(t1-t0):.1f} ms, then wait {1e3*(t2-t1):.1f} ms (total {1e3*(t2-t0):.1f} ms)")
+if "--profile" in sys.orig_argv if hasattr(sys, "orig_argv") else False:
+    pass
+import cProfile, pstats, os
+if os.environ.get("MDT_ISSUE_PROFILE") == "1":
+    pr = cProfile.Profile()
+    pr.enable()
+    step()
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(18)

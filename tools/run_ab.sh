@@ -1,7 +1,8 @@
 set -e
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-cp gpurun_lib_new.so multimodaldiscussiontransformer_amd/libmdt_hip.so
-timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k gemm > gpurun_out/t69.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_shapes_g1 -- python3 tools/gemm_pmc_shapes.py > gpurun_out/pmc_shapes_g1.log 2>&1
-python tools/gemm_pmc_shapes.py --report gpurun_out/pmc_shapes_g1 > gpurun_out/pmc_g1.log 2>&1
-bash tools/ab_libs.sh
+out=gpurun_out/ab72.log; rm -f $out
+for cfg in "GPU_MAX_HW_QUEUES=4 MDT_TWO_STREAMS=0" "GPU_MAX_HW_QUEUES=8 MDT_TWO_STREAMS=0" "GPU_MAX_HW_QUEUES=4 MDT_TWO_STREAMS=1" "GPU_MAX_HW_QUEUES=8 MDT_TWO_STREAMS=1"; do
+  echo "== $cfg" >> $out
+  env $cfg timeout -k 10 300 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-gemm-timer --no-selfcheck 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['ms_per_step'], d['host_issue_ms_per_step'])" >> $out
+done
