@@ -381,10 +381,20 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
 // columns per lane (odd 16-lane rows of tile j trade places with even rows of tile j + 1), so bias, saved
 // pre-activation, residual and output all move as 16-byte vectors covering 64 contiguous bytes of 16 rows
 // per wave instruction — no LDS parking, no workgroup barrier, and no wave waits for another one.
-template <int NJP>   // NJP pairs of 16-column tiles per wave: 2 (128x64 blocks) or 4 (128x128 blocks)
+//
+// EPK >= 0: the epilogue flag set is a compile-time constant (the hot combinations of a training step get their own
+// kernel instantiation, see launch_pp256).  The code is then straight-line, which is what lets the vectors the
+// epilogue READS — saved GELU derivative, residual — be requested ahead: 8 row groups of the first column pair up
+// front, and a row group that has consumed its vector requests the one of the next column pair into the same
+// registers (32 VGPRs live).  With runtime flags (EPK = -1) every such load sits in its own branch and the compiler
+// follows it with s_waitcnt vmcnt(0), which on this in-order counter also waits for the store of the row group
+// before: 16 serialised memory round trips per tile (0.53-0.90 PFLOP/s in situ on the residual / saved-derivative
+// GEMMs against 1.05-1.13 on the same shapes without).
+template <int NJP, int EPK = -1>   // NJP pairs of 16-column tiles per wave: 2 (128x64 blocks) or 4 (128x128 blocks)
 __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc)[8][2 * NJP], int lane, int64_t m0w, int64_t n0w) {
   const int c = lane & 15, g = lane >> 4;
-  const int ep = p.epilogue;
+  const int ep = EPK >= 0 ? EPK : p.epilogue;
+  constexpr int PRE_KIND = EPK < 0 ? 0 : (EPK & (MDT_EPI_MULAUX | MDT_EPI_DGELU)) ? 1 : (EPK & MDT_EPI_RESIDUAL) ? 2 : (EPK & MDT_EPI_ACCUM) ? 3 : 0;
   int64_t gcs[NJP];
   float bias[NJP][8];
 #pragma unroll
@@ -403,14 +413,26 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
   for (int jp = 0; jp < NJP; ++jp)
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[jp][e] = 0.f;
-  // The eight row groups are expanded by hand (generic lambda over a compile-time index): hipcc does not unroll a
+  auto pre_load = [&](int i, int jp) -> bf16x8 {
+    const bf16_t* base = PRE_KIND == 1 ? (const bf16_t*)p.aux : PRE_KIND == 2 ? (const bf16_t*)p.residual : (const bf16_t*)p.C;
+    const int64_t ld = PRE_KIND == 1 ? p.ldaux : PRE_KIND == 2 ? p.ldr : p.ldc;
+    int64_t gr = m0w + 16 * i + c;
+    gr = gr < p.M ? gr : p.M - 1;                // rows past the end: any valid address, the value is never used
+    return *(const bf16x8*)(base + gr * ld + gcs[jp]);
+  };
+  bf16x8 pre[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) pre[i] = PRE_KIND ? pre_load(i, 0) : bf16x8{};
+  // The row groups are expanded by hand (generic lambda over compile-time indices): hipcc does not unroll a
   // loop around the convergent swap, and a rolled loop indexes the accumulators dynamically = 512 B of scratch per lane.
-  auto row_group = [&](auto ic) __attribute__((always_inline)) {
+  auto row_group = [&](auto ic, auto jc) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
+    constexpr int jp = decltype(jc)::value;
     const int64_t gr = m0w + 16 * i + c;
     const bool live = gr < p.M;
-#pragma unroll
-    for (int jp = 0; jp < NJP; ++jp) {
+    const bf16x8 pv = pre[i];
+    if (PRE_KIND && jp + 1 < NJP) pre[i] = pre_load(i, jp + 1);
+    do {
       float v[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -423,7 +445,7 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
         v[r] = lo;
         v[4 + r] = hi;
       }
-      if (!live) continue;
+      if (!live) break;
       const int64_t gc = gcs[jp];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], p.alpha, bias[jp][e]);
@@ -467,17 +489,17 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
       }
       }
       if (ep & MDT_EPI_MULAUX) {
-        const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + gr * p.ldaux + gc);
+        const bf16x8 u = PRE_KIND == 1 ? pv : *(const bf16x8*)((const bf16_t*)p.aux + gr * p.ldaux + gc);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= (float)u[e];
       }
       if (ep & MDT_EPI_DGELU) {
-        const bf16x8 u = *(const bf16x8*)((const bf16_t*)p.aux + gr * p.ldaux + gc);
+        const bf16x8 u = PRE_KIND == 1 ? pv : *(const bf16x8*)((const bf16_t*)p.aux + gr * p.ldaux + gc);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= gelu_fast_grad((float)u[e]);
       }
       if (ep & MDT_EPI_RESIDUAL) {
-        const bf16x8 r = *(const bf16x8*)((const bf16_t*)p.residual + gr * p.ldr + gc);
+        const bf16x8 r = PRE_KIND == 2 ? pv : *(const bf16x8*)((const bf16_t*)p.residual + gr * p.ldr + gc);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
       }
@@ -487,26 +509,40 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
       }
       bf16_t* cptr = (bf16_t*)p.C + gr * p.ldc + gc;
       if (ep & MDT_EPI_ACCUM) {
-        const bf16x8 o = *(const bf16x8*)cptr;
+        const bf16x8 o = PRE_KIND == 3 ? pv : *(const bf16x8*)cptr;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += (float)o[e];
       }
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-      if (ep & (1 << 20)) continue;                       // diagnostic: no output store
+      if (ep & (1 << 20)) break;                          // diagnostic: no output store
       if (ep & (1 << 21)) {                               // diagnostic: write-through, do not keep the line in L2
         const i32x4 raw = __builtin_bit_cast(i32x4, o);
         asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(cptr), "v"(raw) : "memory");
       } else {
         *(bf16x8*)cptr = o;
       }
-    }
+    } while (false);
   };
-  row_group(std::integral_constant<int, 0>{}); row_group(std::integral_constant<int, 1>{});
-  row_group(std::integral_constant<int, 2>{}); row_group(std::integral_constant<int, 3>{});
-  row_group(std::integral_constant<int, 4>{}); row_group(std::integral_constant<int, 5>{});
-  row_group(std::integral_constant<int, 6>{}); row_group(std::integral_constant<int, 7>{});
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+  using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
+  if constexpr (PRE_KIND != 0) {     // column pair by column pair, so the next pair's vectors are a whole pass ahead
+    auto column_pair = [&](auto jc) __attribute__((always_inline)) {
+      row_group(I0{}, jc); row_group(I1{}, jc); row_group(I2{}, jc); row_group(I3{}, jc);
+      row_group(I4{}, jc); row_group(I5{}, jc); row_group(I6{}, jc); row_group(I7{}, jc);
+    };
+    column_pair(I0{}); column_pair(I1{});
+    if constexpr (NJP > 2) { column_pair(I2{}); column_pair(I3{}); }
+  } else {
+    auto rows = [&](auto ic) __attribute__((always_inline)) {
+      row_group(ic, I0{}); row_group(ic, I1{});
+      if constexpr (NJP > 2) { row_group(ic, I2{}); row_group(ic, I3{}); }
+    };
+    rows(I0{}); rows(I1{}); rows(I2{}); rows(I3{}); rows(I4{}); rows(I5{}); rows(I6{}); rows(I7{});
+  }
   if (ep & MDT_EPI_COLSUM) {   // the 16 lanes of a row group hold 16 rows of the same columns
 #pragma unroll
     for (int jp = 0; jp < NJP; ++jp)
@@ -860,7 +896,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
 // launch / drain that a 12-step (K = 768) tile pays per tile otherwise are gone.  At a boundary the early
 // group takes one extra barrier so both groups run their epilogues at the same time, and the stagger is
 // re-created on entry to the next tile.  bf16 output, split_k == 1, at least PP_DIST steps per tile.
-template <bool A_KM, bool B_KM, int PP_DIST>
+template <bool A_KM, bool B_KM, int PP_DIST, int EPK = -1>
 __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
   constexpr int PP_NB = pp_nb(PP_DIST);
   constexpr int BM = 256, BN = 256;
@@ -1012,7 +1048,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
     if (p.stamps) { s_cyc += __builtin_amdgcn_s_memtime() - t_cyc; s_real += __builtin_amdgcn_s_memrealtime() - t_real; s_nk += nhs / 2; }
     int popped = -1;
     if (dyn && has_next && tid == 0) popped = pop_tile();       // the tile after next; returns while the epilogue runs
-    direct_epilogue<2>(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 64);
+    direct_epilogue<2, EPK>(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 64);
     if (!has_next) break;
     cur = nxt;
     if (dyn) {
@@ -1298,9 +1334,9 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   // 1-3 % per GEMM, 0.6 % on the whole step — the fill is throughput- rather than latency-bound
   if (persist) {
     const size_t lds = (size_t)pp_nb(4) * PP_STAGE;
-#define LPS(A_, B_)                                                                                          \
+#define LPS(A_, B_, E_)                                                                                      \
   {                                                                                                          \
-    auto kern = gemm_bf16_pp256p<A_, B_, 4>;                                                                 \
+    auto kern = gemm_bf16_pp256p<A_, B_, 4, E_>;                                                             \
     static bool attr_set = false;                                                                            \
     if (!attr_set) {                                                                                         \
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
@@ -1312,10 +1348,25 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
     }                                                                                                        \
     hipLaunchKernelGGL(kern, grid, 512, lds, st, p);                                                         \
   }
-    if (!ta && !tb) LPS(false, false)
-    else if (!ta && tb) LPS(false, true)
-    else if (ta && !tb) LPS(true, false)
-    else LPS(true, true)
+    // the epilogue flag sets of a training step get instantiations with the flags folded in (see direct_epilogue);
+    // anything else — eval-mode combinations, diagnostics — runs the runtime-flag kernel
+    constexpr int E_BIAS = MDT_EPI_BIAS, E_DENSE = MDT_EPI_BIAS | MDT_EPI_RESIDUAL | MDT_EPI_DROPOUT,
+                  E_FC1 = MDT_EPI_BIAS | MDT_EPI_GELU | MDT_EPI_AUX_GRAD | MDT_EPI_DROPOUT, E_RES = MDT_EPI_RESIDUAL,
+                  E_DFC2 = MDT_EPI_MULAUX | MDT_EPI_COLSUM;
+    static const bool no_spec = getenv("MDT_GEMM_NO_SPEC") != nullptr;
+    const int e = no_spec ? -2 : p.epilogue;
+    if (!ta && !tb) {
+      if (e == E_BIAS) LPS(false, false, E_BIAS)
+      else if (e == E_DENSE) LPS(false, false, E_DENSE)
+      else if (e == E_FC1 && p.aux) LPS(false, false, E_FC1)
+      else LPS(false, false, -1)
+    } else if (!ta && tb) {
+      if (e == 0) LPS(false, true, 0)
+      else if (e == E_RES) LPS(false, true, E_RES)
+      else if (e == E_DFC2) LPS(false, true, E_DFC2)
+      else LPS(false, true, -1)
+    } else if (ta && !tb) LPS(true, false, -1)
+    else LPS(true, true, -1)
 #undef LPS
     if (p.stamps) {
       report_stamps(p.stamps, nwg, p);

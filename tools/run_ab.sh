@@ -1,8 +1,5 @@
 set -e
-out=gpurun_out/ab72.log; rm -f $out
-for cfg in "GPU_MAX_HW_QUEUES=4 MDT_TWO_STREAMS=0" "GPU_MAX_HW_QUEUES=8 MDT_TWO_STREAMS=0" "GPU_MAX_HW_QUEUES=4 MDT_TWO_STREAMS=1" "GPU_MAX_HW_QUEUES=8 MDT_TWO_STREAMS=1"; do
-  echo "== $cfg" >> $out
-  env $cfg timeout -k 10 300 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-gemm-timer --no-selfcheck 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['ms_per_step'], d['host_issue_ms_per_step'])" >> $out
-done
+cp gpurun_lib_new.so multimodaldiscussiontransformer_amd/libmdt_hip.so
+timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py tests/test_dropout_gpu.py -m gpu -x -q > gpurun_out/t78.log 2>&1
+MDT_BENCH_GEMM_TABLE=1 timeout -k 10 300 python bench.py --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/b78.log 2> gpurun_out/b78.err
+bash tools/ab_libs.sh
