@@ -1351,7 +1351,7 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
     // the epilogue flag sets of a training step get instantiations with the flags folded in (see direct_epilogue);
     // anything else — eval-mode combinations, diagnostics — runs the runtime-flag kernel
     constexpr int E_BIAS = MDT_EPI_BIAS, E_DENSE = MDT_EPI_BIAS | MDT_EPI_RESIDUAL | MDT_EPI_DROPOUT,
-                  E_FC1 = MDT_EPI_BIAS | MDT_EPI_GELU | MDT_EPI_AUX_GRAD | MDT_EPI_DROPOUT, E_RES = MDT_EPI_RESIDUAL,
+                  E_FC1 = MDT_EPI_BIAS | MDT_EPI_GELU | MDT_EPI_AUX_GRAD /* HF blocks have no activation dropout */, E_RES = MDT_EPI_RESIDUAL,
                   E_DFC2 = MDT_EPI_MULAUX | MDT_EPI_COLSUM;
     static const bool no_spec = getenv("MDT_GEMM_NO_SPEC") != nullptr;
     const int e = no_spec ? -2 : p.epilogue;
