@@ -1273,8 +1273,8 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   p.tile_queue = nullptr;
   if (persist) {
     // MDT_GEMM_DYNAMIC=1: dynamic tile queue instead of the static round-robin walk (in-call A/B on an otherwise idle
-    // chip: static is 1.5 % faster — two more barriers per tile, and raided tiles leave their XCD's L2 — so dynamic
-    // is what ddp.py selects when RCCL kernels share the chip).  512 queue sets are used in turn, each zeroed once
+    // chip: static is 1.5 % faster — two more barriers per tile, and raided tiles leave their XCD's L2; the queue is
+    // there for a node where other kernels — RCCL — hold compute units for long, see ddp.py).  512 queue sets are used in turn, each zeroed once
     // here and put back to zero by the last workgroup of the launch that used it (launches of the two branch streams
     // run concurrently, at most a few dozen launches apart in issue order).
     static int* queues = nullptr;

@@ -181,14 +181,14 @@ class DataParallel:
         params = [p for p in model.parameters() if p.requires_grad and hasattr(p, "main_grad")]
         stream = torch.cuda.Stream() if flat.is_cuda else None
         self.bucketer = GradientBucketer(params, flat, bucket_mb << 20, process_group, stream)
-        if self.bucketer.world > 1:
-            # RCCL's kernels run beside backward and take whole CUs (a ping-pong GEMM workgroup leaves no LDS for a
-            # neighbour).  The persistent GEMM with a STATIC tile walk assumes one resident workgroup per CU from start
-            # to end: with some CUs busy elsewhere its statically assigned tiles would wait for a whole pass.  Its
-            # dynamic tile queue lets a late or time-shared CU simply take fewer tiles (idle chip, in-call A/B: static
-            # +1.5 % over dynamic, dynamic +1.5 % over one tile per workgroup).
-            import os
-            os.environ.setdefault("MDT_GEMM_DYNAMIC", "1")
+        # RCCL's kernels run beside backward and take whole CUs (a ping-pong GEMM workgroup leaves no LDS for a neighbour).
+        # The persistent GEMM's STATIC tile walk assumes one resident workgroup per CU: a workgroup whose CU is busy
+        # elsewhere starts late and finishes its statically assigned tiles late.  Its dynamic tile queue
+        # (MDT_GEMM_DYNAMIC=1) lets such a CU simply take fewer tiles, but costs 1.5 % on an idle chip and 4 % once the
+        # two branch streams overlap (155.1 against 149.1 ms, RCCL path forced on one GPU) — more than the 3-7 % of a
+        # step during which the ~13 bucket all-reduces are resident at all, and with two streams the other branch's
+        # kernels fill a CU that waits.  The static walk therefore stays the default at every world size; the switch
+        # is for a node where the collectives turn out to be slow.
         if flat.is_cuda and getattr(ge, "two_streams", False):
             from . import engine
             self.bucketer.compute_streams = [torch.cuda.current_stream(), engine.side_stream(flat.device)]
