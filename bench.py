@@ -213,14 +213,41 @@ def selfcheck():
     ur = u.clone().requires_grad_(True)
     (F.gelu(ur) * m).sum().backward()
     torch.testing.assert_close(aux.float(), ur.grad, **tol)
-    del ur, m, aux, h
+    del m, h
+    # the flag sets of a training step that have their own persistent-kernel instantiation (compile-time epilogues)
+    h = ops.gemm(a, w, bias=bias, aux=aux, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD)        # fc1 of the BERT / ViT blocks
+    torch.testing.assert_close(h.float(), F.gelu(u), **tol)
+    ur.grad = None
+    F.gelu(ur).sum().backward()
+    torch.testing.assert_close(aux.float(), ur.grad, **tol)
+    del ur, h
     dy = rn(M, N, sc=0.1)
     dx = ops.gemm(dy, w, trans_b=True)                              # dgrad: [M, N] x [N, K]
     torch.testing.assert_close(dx.float(), dy.float() @ w.float(), **tol)
+    res_k = rn(M, K, sc=0.5)
+    dx = ops.gemm(dy, w, trans_b=True, residual=res_k)              # dgrad + residual gradient
+    torch.testing.assert_close(dx.float(), dy.float() @ w.float() + res_k.float(), **tol)
+    del dx, res_k
+    w2 = rn(K, N, sc=0.05)                                          # fc2: [K_out = 768, 3072]
+    dz = rn(M, K, sc=0.1)
+    cs = torch.zeros(N, device="cuda", dtype=torch.float32)
+    du = ops.gemm(dz, w2, trans_b=True, aux=aux, epilogue=ops.EPI_MULAUX, colsum=cs)       # fc2 dgrad x saved derivative + fc1 bias gradient
+    du_ref = (dz.float() @ w2.float()) * aux.float()
+    torch.testing.assert_close(du.float(), du_ref, **tol)
+    torch.testing.assert_close(cs, du_ref.sum(0), atol=2.0, rtol=3e-2)
+    del du, du_ref, cs
+    hh = rn(M, N, sc=0.3)
+    res2, b2 = rn(M, K, sc=0.5), rn(K)
+    m2 = ops.dropout_mask(M * K, 0.4, 77).view(M, K).float() / 0.6
+    y = ops.gemm(hh, w2, bias=b2, residual=res2, drop_p=0.4, drop_seed=77)                  # fc2 / o projection: dropout(x W^T + b) + residual
+    torch.testing.assert_close(y.float(), (hh.float() @ w2.float().t() + b2.float()) * m2 + res2.float(), **tol)
+    y = ops.gemm(hh, w2, bias=b2)                                                           # qkv-style: bias only
+    torch.testing.assert_close(y.float(), hh.float() @ w2.float().t() + b2.float(), **tol)
+    del y, hh, res2, m2, w2, dz, aux
     gw = torch.zeros(N, K, device="cuda", dtype=torch.float32)
     ops.gemm(dy, a, trans_a=True, trans_b=True, out=gw, epilogue=ops.EPI_ATOMIC, split_k=7)
     torch.testing.assert_close(gw, dy.float().t() @ a.float(), atol=0.5, rtol=2e-2)
-    del dy, dx, gw, u, a, w
+    del dy, gw, u, a, w
     for (nseq, S) in ((96, 104), (24, 201)):
         H, hd, p, seed = 12, 64, 0.3, 4242
         D = H * hd

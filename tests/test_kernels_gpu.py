@@ -175,6 +175,41 @@ def test_gemm_bf16_out_big_tiles(ops, M, N, K, tb, monkeypatch):
     torch.testing.assert_close(cs, full.sum(0), atol=1.0, rtol=2e-2)
 
 
+def test_gemm_training_epilogues_persistent(ops):
+    """The epilogue flag sets of a training step each have their own instantiation of the persistent 256x256 kernel
+    (flags folded at compile time, operand vectors requested a column pair ahead): bias; bias + dropout + residual;
+    bias + GELU + saved derivative; plain and residual input gradients; saved-derivative multiply + column sums.
+    More tiles than CUs (persistent walk) and a ragged last row tile."""
+    M, N, K = 16640 + 13, 1280, 768
+    bf = torch.bfloat16
+    a, w, bias = dev(rnd(M, K, seed=1).to(bf)), dev(rnd(N, K, seed=2, scale=0.05).to(bf)), dev(rnd(N, seed=3).to(bf))
+    tol = dict(atol=0.06, rtol=2e-2)
+    u = a.float() @ w.float().t() + bias.float()
+    torch.testing.assert_close(ops.gemm(a, w, bias=bias).float(), u, **tol)                                   # 1
+    aux = torch.empty(M, N, device="cuda", dtype=bf)
+    h = ops.gemm(a, w, bias=bias, aux=aux, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD)                          # 259
+    torch.testing.assert_close(h.float(), F.gelu(u), **tol)
+    ur = u.clone().requires_grad_(True)
+    F.gelu(ur).sum().backward()
+    torch.testing.assert_close(aux.float(), ur.grad, **tol)
+    res = dev(rnd(M, N, seed=4, scale=0.5).to(bf))
+    mask = ops.dropout_mask(M * N, 0.4, 77).view(M, N).float() / 0.6
+    y = ops.gemm(a, w, bias=bias, residual=res, drop_p=0.4, drop_seed=77)                                     # 69
+    torch.testing.assert_close(y.float(), u * mask + res.float(), **tol)
+    dy = dev(rnd(M, N, seed=5, scale=0.1).to(bf))
+    dref = dy.float() @ w.float()
+    torch.testing.assert_close(ops.gemm(dy, w, trans_b=True).float(), dref, **tol)                            # 0
+    resk = dev(rnd(M, K, seed=6, scale=0.5).to(bf))
+    torch.testing.assert_close(ops.gemm(dy, w, trans_b=True, residual=resk).float(), dref + resk.float(), **tol)   # 4
+    w2 = dev(rnd(K, N, seed=7, scale=0.05).to(bf))
+    dz = dev(rnd(M, K, seed=8, scale=0.1).to(bf))
+    cs = torch.zeros(N, device="cuda", dtype=torch.float32)
+    du = ops.gemm(dz, w2, trans_b=True, aux=aux, epilogue=ops.EPI_MULAUX, colsum=cs)                          # 640
+    du_ref = (dz.float() @ w2.float()) * aux.float()
+    torch.testing.assert_close(du.float(), du_ref, **tol)
+    torch.testing.assert_close(cs, du_ref.sum(0), atol=1.0, rtol=3e-2)
+
+
 def test_colsum_cast_transpose(ops):
     x = rnd(1037, 200, seed=9)
     torch.testing.assert_close(ops.colsum(dev(x)).cpu(), x.sum(0), atol=1e-3, rtol=1e-5)
