@@ -38,6 +38,11 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+if os.environ.get("MDT_SINGLE_DEVICE") == "1":
+    # rehearsal with several ranks on ONE card: 8 hardware queues per process oversubscribe the card's queue slots and the
+    # cross-queue event waits of the step then never resolve (observed: both ranks stuck in the first gradient
+    # all-reduce).  HIP's default of 4 per process is the safe value when processes share a GPU.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 import multimodaldiscussiontransformer_amd  # noqa: E402,F401  (sets GPU_MAX_HW_QUEUES before the first device call)
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0
@@ -333,6 +338,9 @@ def selfcheck_model(model, pb, build_fp32, crit=None):
 
 
 def main():
+    if os.environ.get("MDT_BENCH_WATCHDOG"):      # diagnostics: dump every thread's Python stack and exit if the run takes longer
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MDT_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)

@@ -9,6 +9,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")     # two processes share the card: stay within its hardware queue slots
 
 from multimodaldiscussiontransformer_amd import synthetic  # noqa: E402
 from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy  # noqa: E402
