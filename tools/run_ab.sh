@@ -1,5 +1,8 @@
+# Template for an in-call A/B on the GPU box (boxes differ by several per cent: both arms must run inside ONE gpurun call).
+# Usage: gpurun --timeout 900 -- 'bash tools/run_ab.sh'; edit the list of environment settings to compare.
 set -e
-export MDT_DDP_FORCE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0
-MDT_GEMM_DYNAMIC=1 timeout -k 10 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/b83_dyn.log 2>&1
-MDT_GEMM_DYNAMIC=0 timeout -k 10 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/b83_static.log 2>&1
-MDT_GEMM_DYNAMIC=1 timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py tests/test_dropout_gpu.py tests/test_model_gpu.py -m gpu -x -q > gpurun_out/t83.log 2>&1
+out=gpurun_out/ab.log; rm -f $out
+for cfg in "MDT_TWO_STREAMS=0" "MDT_TWO_STREAMS=1" "MDT_TWO_STREAMS=0" "MDT_TWO_STREAMS=1"; do
+  echo "== $cfg" >> $out
+  env $cfg timeout -k 10 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-selfcheck --no-gemm-timer 2>/dev/null | cut -c1-160 >> $out
+done
