@@ -84,3 +84,60 @@ def test_launcher_trains_and_loss_decreases(tmp_path):
     sd = torch.load(ck)["model"]
     assert "encoder.graph_encoder.layers.0.layers.0.self_attn.q_proj.weight" in sd
     assert "encoder.graph_encoder.fusion_layers.0.fusion_layers.0.bert_encoder.attention.self.query.weight" in sd
+
+
+def test_rccl_bucketed_exchange_world1_equals_plain_backward(monkeypatch):
+    """The overlapped gradient exchange as it runs on a node — static buckets all-reduced in place by RCCL on the
+    exchange stream while the two branch streams are still in backward — at world size 1, where the sum over ranks is
+    the identity: the arena after three steps must equal the arena of a run without any exchange."""
+    import torch.distributed as dist
+    from multimodaldiscussiontransformer_amd import synthetic
+    from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
+    from multimodaldiscussiontransformer_amd.data.packer import pack_batch
+    from multimodaldiscussiontransformer_amd.ddp import DataParallel
+    from multimodaldiscussiontransformer_amd.models import GraphormerModel
+    from oracle import cases
+    from tests.util_model import fill_hash_weights, model_args
+    hp = cases.tiny_hparams("A")
+    trees = synthetic.make_trees(6, 9, seed=271, variable=True, seq_len=16, vocab_size=hp.vocab_size, image_frac=0.5,
+                                 image_size=hp.image_size, min_len=3)
+    crit = GraphPredictionNodeCrossEntropy(None, positive_weight=1.5, negative_weight=1.0)
+    pb = pack_batch(trees, 5)
+
+    def run(force):
+        monkeypatch.setenv("MDT_DDP_FORCE", "1" if force else "0")
+        model = GraphormerModel.build_model(model_args(hp), task=None)
+        fill_hash_weights(model)
+        model = model.cuda().eval()
+        dp = DataParallel(model, bucket_mb=8)
+        assert dp.bucketer.active == force
+        out = None
+        for step in range(3):
+            dp.zero_grad()
+            loss, n, _ = crit(model, {"nsamples": len(trees), "net_input": {"batched_data": pb.batched_data}})
+            loss.backward()
+            scal = torch.zeros(6, device="cuda")
+            scal[0] = loss.detach().float()
+            scal[1].fill_(float(n))
+            dp.finish_backward(scal)
+            if force and step > 0:
+                assert len(dp.bucketer.bucket_ends) > 2
+        torch.cuda.synchronize()
+        return {n_: p.main_grad.detach().clone() for n_, p in model.named_parameters() if hasattr(p, "main_grad")}
+
+    plain = run(False)
+    created = not dist.is_initialized()
+    if created:
+        try:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1)
+        except Exception as e:                     # no RCCL transport on this box: nothing to exercise
+            import pytest
+            pytest.skip(f"cannot create a world-size-1 RCCL group here: {e}")
+    try:
+        forced = run(True)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert set(plain) == set(forced)
+    for n_ in plain:
+        torch.testing.assert_close(forced[n_], plain[n_], atol=2e-5 * max(1.0, float(plain[n_].abs().max())), rtol=1e-4, msg=n_)
