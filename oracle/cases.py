@@ -53,3 +53,70 @@ def tiny_trees(kind, hp):
     return trees
 
 
+
+
+# ----------------------------------------------------------------------------- real-geometry cases
+# "C2": BASELINE.json configs[1] at its TRUE geometry — BERT-base + ViT-B/16 split 6 + 6, 6 executed graph layers,
+#       FFN 3072, L = 100 tokens (S = 104 with the bottleneck tokens), 224-px images (P = 197, S = 201), one bushy
+#       64-comment tree (T = 65) with 25 % image comments.  The reference itself runs this case (D = 768).
+# "C4": BASELINE.json configs[3] mDT-large SHAPES — D 1024, 16 heads, FFN 4096, ViT-L/14 (P = 257, S = 261), one
+#       128-comment deep-thread tree (T = 129, banded -inf mask at spatial_pos_max = 5); the layer count is cut to
+#       2 + 2 (1 executed graph layer pair) so that the CPU oracle finishes in seconds.  The reference cannot run it
+#       (768 is a literal there): oracle only.
+# "M":  the tiny "A" shapes with many labelled comments and a classifier bias that centres the logit margins, so that
+#       predictions are MIXED (TP, FP, FN, TN all non-zero) and a sign flip in one logit column cannot pass.
+def real_hparams(kind):
+    if kind == "C2":
+        return R.hparams(dim=768, enc_heads=12, graph_heads=12, enc_ffn=3072, graph_ffn=768, text_layers=12,
+                         vit_layers=12, num_fusion_layers=5, num_fusion_stack=1, num_graph_stack=1, num_bottleneck=4,
+                         vocab_size=30522, max_pos=512, image_size=224, patch=16, pos_weight=1.5, neg_weight=1.0)
+    if kind == "C4":
+        return R.hparams(dim=1024, enc_heads=16, graph_heads=16, enc_ffn=4096, graph_ffn=1024, text_layers=4,
+                         vit_layers=4, num_fusion_layers=1, num_fusion_stack=1, num_graph_stack=1, num_bottleneck=4,
+                         vocab_size=30522, max_pos=512, image_size=224, patch=14, pos_weight=1.5, neg_weight=1.0)
+    if kind == "M":
+        return tiny_hparams("A")
+    raise KeyError(kind)
+
+
+def _label_many(trees, every=2):
+    for i, t in enumerate(trees):
+        n = len(t["parent"])
+        t["y_mask"][:] = False
+        lab = list(range(i % every, n, every))
+        t["y_mask"][lab] = True
+        t["y"] = np.asarray([((k * 7 + i) % 3 == 0) for k in range(len(lab))], dtype=np.float32)
+    return trees
+
+
+def real_trees(kind, hp):
+    if kind == "C2":
+        rng = np.random.Generator(np.random.PCG64(2024))
+        trees = [synthetic.make_tree(64, rng, seq_len=100, vocab_size=hp.vocab_size, image_frac=0.25,
+                                     image_size=hp.image_size, shape="bushy", min_len=8)]
+        return _label_many(trees, every=2)
+    if kind == "C4":
+        rng = np.random.Generator(np.random.PCG64(4096))
+        trees = [synthetic.make_tree(128, rng, seq_len=100, vocab_size=hp.vocab_size, image_frac=0.125,
+                                     image_size=hp.image_size, shape="deep", min_len=8)]
+        return _label_many(trees, every=2)
+    if kind == "M":
+        rng = np.random.Generator(np.random.PCG64(515))
+        spec = ((8, 0.25, "bushy"), (7, 0.0, "deep"), (5, 0.4, "bushy"), (4, 0.0, "deep"))
+        trees = [synthetic.make_tree(n, rng, seq_len=16, vocab_size=hp.vocab_size, image_frac=f, image_size=hp.image_size,
+                                     shape=s, min_len=3) for n, f, s in spec]
+        return _label_many(trees, every=1)
+    raise KeyError(kind)
+
+
+# node_classifier.bias per case: minus / plus half the median logit margin of the hash-weight model (measured once with
+# the oracle, tools/margin_probe.py), so that about half of the comments are predicted positive.  Applied identically
+# to the reference (gen_golden), the oracle (make_weights) and the product (tests.util_model.fill_hash_weights).
+_BIAS_SHIFT = {"C2": 0.68, "C4": 0.0874, "M": 1.0912}
+
+
+def weight_overrides(kind):
+    s = _BIAS_SHIFT.get(kind)
+    if s is None:
+        return {}
+    return {"node_classifier.bias": np.asarray([s / 2.0, -s / 2.0], dtype=np.float32)}

@@ -225,12 +225,15 @@ def canonical(name: str) -> str:
     return name
 
 
-def fill_params(module: nn.Module, prefix: str = ""):
+def fill_params(module: nn.Module, prefix: str = "", overrides=None):
     names = {}
     with torch.no_grad():
         for n, p in module.named_parameters():
             c = prefix + canonical(n)
-            p.copy_(torch.from_numpy(hashinit.param(c, tuple(p.shape))))
+            if overrides and c in overrides:
+                p.copy_(torch.from_numpy(np.asarray(overrides[c]).reshape(tuple(p.shape)).copy()))
+            else:
+                p.copy_(torch.from_numpy(hashinit.param(c, tuple(p.shape))))
             names[c] = p
     return names
 
@@ -420,10 +423,15 @@ def case_graph_modules(mods):
         np.savez_compressed(os.path.join(OUT, f"graph_modules_d{D}.npz"), **out)
 
 
-def case_full_model(mods, models, collator_mod, pre, updown, loss_mod, metrics):
-    for kind in ("A", "B"):
-        hp = tiny_hparams(kind)
-        trees = tiny_trees(kind, hp)
+def case_full_model(mods, models, collator_mod, pre, updown, loss_mod, metrics, kinds=("A", "B", "M", "C2")):
+    for kind in kinds:
+        if kind in ("A", "B"):
+            hp, over, fname = tiny_hparams(kind), {}, f"full_tiny768_{kind}.npz"
+            trees = tiny_trees(kind, hp)
+        else:       # "M": tiny shapes, mixed predictions; "C2": BASELINE.json configs[1] at its true geometry
+            hp, over = cases.real_hparams(kind), cases.weight_overrides(kind)
+            trees = cases.real_trees(kind, hp)
+            fname = {"M": "full_tiny768_M.npz", "C2": "full_c2_real.npz"}[kind]
         items = ref_items_from_trees(trees, pre, updown)
         batch = ref_collate(items, collator_mod, 5)
         enc = build_reference_encoder(mods, hp)
@@ -437,7 +445,7 @@ def case_full_model(mods, models, collator_mod, pre, updown, loss_mod, metrics):
         nn.Module.__init__(model)
         model.encoder = genc
         model.train()                       # dropout p = 0 everywhere; train mode like the launch
-        named = fill_params(enc)
+        named = fill_params(enc, overrides=over)
         # oracle shapes and reference shapes must agree name by name
         shapes = R.param_shapes(hp)
         ref_shapes = {n: tuple(p.shape) for n, p in named.items()}
@@ -470,8 +478,10 @@ def case_full_model(mods, models, collator_mod, pre, updown, loss_mod, metrics):
             out["metric/" + k] = np.asarray(v)
         grad_summary(named, out)
         out["n_trainable_with_grad"] = np.asarray(sum(1 for p in named.values() if p.grad is not None))
-        np.savez_compressed(os.path.join(OUT, f"full_tiny768_{kind}.npz"), **out)
-        print(kind, "loss", float(lossv), "logits", logits[:2].tolist(), "F1", metrics.LOG.get("f1"))
+        np.savez_compressed(os.path.join(OUT, fname), **out)
+        print(kind, "loss", float(lossv), "logits", logits[:2].tolist(), "F1", metrics.LOG.get("f1"),
+              {k: int(log[k]) for k in ("ncorrect", "num_positive_correct", "total_positive", "num_pred_positive")},
+              "n", sample_size, flush=True)
 
 
 def case_fusion_layer(mods):
@@ -523,12 +533,16 @@ def case_fusion_layer(mods):
 
 
 def main():
+    only = sys.argv[1:]          # e.g. `python -m oracle.gen_golden full:M,C2` regenerates just those cases
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     metrics = install_fairseq_standins()
     mods, models, collator_mod, pre, loss_mod = mount_reference()
     updown = load_updown_functions()
+    if only and only[0].startswith("full:"):
+        case_full_model(mods, models, collator_mod, pre, updown, loss_mod, metrics, kinds=tuple(only[0][5:].split(",")))
+        return
     case_structure(pre, collator_mod, updown)
     print("structure done")
     case_graph_modules(mods)

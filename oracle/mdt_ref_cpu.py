@@ -138,11 +138,15 @@ def param_shapes(hp) -> dict:
     return s
 
 
-def make_weights(hp, dtype=torch.float32, requires_grad=True) -> dict:
+def make_weights(hp, dtype=torch.float32, requires_grad=True, overrides=None) -> dict:
+    """``overrides``: {canonical name: array} replacing the hash fill (oracle/cases.py weight_overrides)."""
     from . import hashinit
     W = {}
     for name, shape in param_shapes(hp).items():
-        t = torch.from_numpy(hashinit.param(name, shape)).to(dtype)
+        if overrides and name in overrides:
+            t = torch.from_numpy(overrides[name].reshape(shape).copy()).to(dtype)
+        else:
+            t = torch.from_numpy(hashinit.param(name, shape)).to(dtype)
         W[name] = t.requires_grad_(requires_grad)
     return W
 

@@ -158,13 +158,27 @@ def test_fusion_layer(golden_dir):
             assert abs(float(mine.norm()) - gn) <= 2e-4 * max(1.0, gn), (n, float(mine.norm()), gn)
 
 
-@pytest.mark.parametrize("kind", ["A", "B"])
+def full_case(kind):
+    """→ (golden file name or None, hparams, trees, weight overrides) of a full-model case (oracle/cases.py)."""
+    if kind in ("A", "B"):
+        hp = cases.tiny_hparams(kind)
+        return f"full_tiny768_{kind}.npz", hp, cases.tiny_trees(kind, hp), {}
+    hp = cases.real_hparams(kind)
+    fname = {"M": "full_tiny768_M.npz", "C2": "full_c2_real.npz", "C4": None}[kind]
+    return fname, hp, cases.real_trees(kind, hp), cases.weight_overrides(kind)
+
+
+@pytest.mark.parametrize("kind", ["A", "B", "M", "C2"])
 def test_full_model(golden_dir, kind):
-    g = _load(golden_dir, f"full_tiny768_{kind}.npz")
-    hp = cases.tiny_hparams(kind)
-    trees = cases.tiny_trees(kind, hp)
+    """The oracle against the REAL reference's outputs.  "M": mixed predictions (TP, FP, FN all non-zero);
+    "C2": BASELINE.json configs[1] at its true geometry (L 100, 224-px images, FFN 3072, 6 + 6 layers, 64-comment tree)."""
+    fname, hp, trees, over = full_case(kind)
+    g = _load(golden_dir, fname)
+    if kind in ("M", "C2"):
+        tp, predp, totp = int(g["log/num_positive_correct"]), int(g["log/num_pred_positive"]), int(g["log/total_positive"])
+        assert tp > 0 and predp > tp and totp > tp and int(g["log/ncorrect"]) > tp      # TP, FP, FN, TN all present
     batch = R.to_torch_batch(S.collate(trees, 5))
-    W = R.make_weights(hp)
+    W = R.make_weights(hp, overrides=over)
     text, bn, glob = R.encoder_forward(W, hp, batch)
     np.testing.assert_allclose(text[:, :3, :64].detach().numpy(), g["enc/text_slice"], atol=1e-4)
     np.testing.assert_allclose(bn.detach().numpy(), g["enc/bn"], atol=1e-4)

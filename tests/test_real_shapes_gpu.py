@@ -1,0 +1,174 @@
+"""Model-level parity at the REAL geometries of BASELINE.json (not the toy fixtures of test_model_gpu.py):
+
+  "C2"  configs[1]: BERT-base + ViT-B/16 split 6 + 6, FFN 3072, 6 executed graph layers, L = 100 (S = 104 / ragged),
+        224-px images (P = 197, S = 201), one bushy 64-comment tree (T = 65), 25 % image comments — the shapes at
+        which the 256x256 persistent GEMM, the split-K weight gradient, attn_bwd_v3's 64-key chunking and the ragged
+        offsets engage.  Checked against the REAL reference's outputs (tests/golden/full_c2_real.npz, made by
+        oracle/gen_golden.py) and, tensor by tensor, against the oracle.
+  "C4"  configs[3] mDT-large shapes: D 1024, 16 heads, FFN 4096, ViT-L/14 (P = 257, S = 261), one 128-comment
+        deep-thread tree (T = 129, banded -inf mask).  Layers cut to 2 + 2 so the CPU oracle takes seconds; the
+        reference cannot run D != 768, so the oracle (pinned at D = 768 by the goldens) is the checker.
+  "M"   tiny shapes, mixed predictions (TP / FP / FN / TN all non-zero).
+
+fp32: north_star's 1e-3 gate on logits and on EVERY parameter gradient, both text layouts; counters / F1 exact.
+bf16: logits within 0.05, every parameter gradient within a relative L2 of BF16_GRAD_REL_L2 of the fp32 oracle run on
+the same bf16-rounded weights (magnitude AND direction), small tensors included.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mdt_ref_cpu as R
+from oracle import structure as S
+from tests.test_oracle_golden import full_case
+from tests.util_model import fill_hash_weights, model_args, named_canonical_params, split_qkv_grad
+
+pytestmark = pytest.mark.gpu
+
+BF16_GRAD_REL_L2 = 3e-2      # per parameter tensor, vs the fp32 oracle on bf16-rounded weights
+BF16_LOGIT_ABS = 5e-2
+
+_ORACLE = {}
+
+
+def oracle_run(kind, rounded: bool):
+    """fp32 oracle forward + backward of a case (cached: the C2 / C4 passes take ~10-20 s of host CPU each)."""
+    key = (kind, rounded)
+    if key not in _ORACLE:
+        torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+        fname, hp, trees, over = full_case(kind)
+        W = R.make_weights(hp, overrides=over)
+        if rounded:
+            W = {n: w.detach().bfloat16().float().requires_grad_(True) for n, w in W.items()}
+        ref_b = S.collate(trees, 5)
+        batch = R.to_torch_batch(ref_b)
+        logits, glob = R.model_forward(W, hp, batch)
+        loss, counters = R.node_cross_entropy(logits, batch["y"], batch["y_mask"], hp)
+        loss.backward()
+        grads = {n: (None if w.grad is None else w.grad.detach()) for n, w in W.items()}
+        _ORACLE[key] = dict(hp=hp, trees=trees, over=over, fname=fname, ref_b=ref_b, logits=logits.detach(),
+                            glob=glob.detach(), loss=float(loss), counters=counters, grads=grads)
+    return _ORACLE[key]
+
+
+def product_run(kind, dtype, ragged, main_grad=False):
+    from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
+    from multimodaldiscussiontransformer_amd.data.packer import pack_batch
+    from multimodaldiscussiontransformer_amd.models import GraphormerModel
+    fname, hp, trees, over = full_case(kind)
+    model = GraphormerModel.build_model(model_args(hp), task=None)
+    fill_hash_weights(model, overrides=over)
+    model = model.cuda().to(dtype)
+    model.train()                                            # dropout p = 0 everywhere; train mode like the launch
+    model.encoder.graph_encoder.ragged_tokens = ragged
+    if main_grad:
+        model.prepare_main_grads()
+    pb = pack_batch(trees, 5)
+    crit = GraphPredictionNodeCrossEntropy(None, positive_weight=hp.pos_weight, negative_weight=hp.neg_weight)
+    loss, sample_size, log = crit(model, {"nsamples": len(trees), "net_input": {"batched_data": pb.batched_data}})
+    loss.backward()
+    with torch.no_grad():
+        logits, glob = model(pb.batched_data)
+    torch.cuda.synchronize()
+    return model, pb, float(loss.detach()), sample_size, log, logits, glob
+
+
+@pytest.mark.parametrize("ragged", [False, True], ids=["padded", "ragged"])
+@pytest.mark.parametrize("kind", ["M", "C2", "C4"])
+def test_fp32_real_shapes_vs_reference_golden_and_oracle(golden_dir, kind, ragged):
+    from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
+    o = oracle_run(kind, rounded=False)
+    model, pb, loss, sample_size, log, logits, glob = product_run(kind, torch.float32, ragged)
+    for k in ("attn_bias", "spatial_pos", "in_degree", "x_token_mask", "x", "x_attention_mask", "x_image_indexes", "y_mask"):
+        assert np.array_equal(pb.batched_data[k].cpu().numpy(), o["ref_b"][k]), k           # integer side: bit-exact
+    grads = {n: p.grad for n, p in named_canonical_params(model).items()}
+    lg = logits.cpu()
+    if o["fname"] is not None:                               # the real reference's outputs
+        g = np.load(os.path.join(golden_dir, o["fname"]))
+        np.testing.assert_allclose(lg.numpy(), g["logits"], atol=1e-3)
+        np.testing.assert_allclose(glob.cpu().numpy(), g["enc/global"], atol=1e-3)
+        assert abs(loss - float(g["loss"])) <= 4e-2          # fp16 loss value: 1 ulp at ~27 is 1.6e-2
+        assert sample_size == int(g["sample_size"])
+        for k in ("ncorrect", "num_positive_correct", "total_positive", "num_pred_positive"):
+            assert int(log[k]) == int(g["log/" + k]), k
+        m = GraphPredictionNodeCrossEntropy.compute_metrics([log])
+        for k in ("accuracy", "recall", "precision", "f1"):
+            assert abs(m[k] - float(g["metric/" + k])) < 1e-6, k
+        assert 0.0 < m["f1"] < 1.0 and 0.0 < m["precision"] < 1.0 and 0.0 < m["recall"] < 1.0   # non-degenerate fixture
+        n_checked = 0
+        for key in [k for k in g.files if k.startswith("gnorm/")]:
+            name = key[len("gnorm/"):]
+            gn = float(g[key])
+            gr = split_qkv_grad(name, grads)
+            if gn < 0:
+                assert gr is None or float(gr.abs().max()) == 0.0, f"{name}: the reference gives no gradient"
+                continue
+            assert gr is not None, name
+            n_checked += 1
+            assert abs(float(gr.double().norm()) - gn) <= 1e-3 * max(1.0, gn), (name, float(gr.norm()), gn)
+            d = float(np.abs(gr.flatten()[:64].float().cpu().numpy() - g["gslice/" + name]).max())
+            assert d <= 1e-3 * max(1.0, gn), (name, d)
+        assert n_checked == int(g["n_trainable_with_grad"])
+    # the oracle, full tensors
+    assert float((lg - o["logits"]).abs().max()) < 1e-3
+    assert float((glob.cpu() - o["glob"]).abs().max()) < 1e-3
+    for k in ("ncorrect", "num_positive_correct", "total_positive", "num_pred_positive"):
+        assert int(log[k]) == o["counters"][k], k
+    c = o["counters"]
+    assert c["num_positive_correct"] > 0 and c["num_pred_positive"] > c["num_positive_correct"] \
+        and c["total_positive"] > c["num_positive_correct"], "fixture predictions must be mixed (TP, FP, FN > 0)"
+    worst = ("", 0.0)
+    n = 0
+    for name, ref in o["grads"].items():
+        gr = split_qkv_grad(name, grads)
+        if ref is None:
+            assert gr is None or float(gr.abs().max()) == 0.0, name
+            continue
+        assert gr is not None, name
+        n += 1
+        scale = max(1.0, float(ref.abs().max()))
+        err = float((gr.float().cpu() - ref).abs().max()) / scale
+        if err > worst[1]:
+            worst = (name, err)
+        assert err <= 1e-3, (name, err)
+    print(f"[{kind} {'ragged' if ragged else 'padded'}] logits |err| {float((lg - o['logits']).abs().max()):.2e}; "
+          f"{n} parameter gradients, worst {worst[1]:.2e} ({worst[0]})")
+
+
+@pytest.mark.parametrize("kind", ["M", "C2", "C4"])
+def test_bf16_real_shapes_vs_fp32_oracle(kind):
+    """The production dtype at the real shapes: bf16 MFMA GEMMs / attention, fp32 softmax, LayerNorm statistics and
+    gradient arena, ragged text, against the fp32 oracle on the same bf16-rounded weights.  Every parameter gradient is
+    held to a relative L2 error (magnitude and direction), biases / LayerNorm / tables included."""
+    o = oracle_run(kind, rounded=True)
+    model, pb, loss, sample_size, log, logits, glob = product_run(kind, torch.bfloat16, True, main_grad=True)
+    lg = logits.float().cpu()
+    d_logit = float((lg - o["logits"]).abs().max())
+    assert d_logit < BF16_LOGIT_ABS, d_logit
+    assert abs(loss - o["loss"]) < 0.15 + 0.01 * abs(o["loss"])
+    # predictions may differ only where the fp32 margin is inside the bf16 logit tolerance
+    margin = (o["logits"][:, 1] - o["logits"][:, 0])
+    pred_ref, pred = margin > 0, (lg[:, 1] - lg[:, 0]) > 0
+    clear = margin.abs() > 2 * BF16_LOGIT_ABS
+    assert bool((pred_ref[clear] == pred[clear]).all())
+    assert int(log["total_positive"]) == o["counters"]["total_positive"]
+    grads = {n: getattr(p, "main_grad", None) for n, p in named_canonical_params(model).items()}
+    rows = []
+    for name, ref in o["grads"].items():
+        if ref is None:
+            continue
+        gr = split_qkv_grad(name, grads)
+        assert gr is not None, name
+        rn = float(ref.double().norm())
+        if rn < 1e-7:
+            assert float(gr.float().norm()) < 1e-4, name
+            continue
+        rel = float((gr.float().cpu().double() - ref.double()).norm()) / rn
+        rows.append((rel, name, rn, ref.numel()))
+    rows.sort(reverse=True)
+    print(f"[{kind} bf16] logits |err| {d_logit:.3e}; {len(rows)} gradients; worst rel-L2: "
+          + "; ".join(f"{n} {r:.3e} (|g| {rn:.2e}, {ne} el)" for r, n, rn, ne in rows[:6]))
+    bad = [(n, r) for r, n, _, _ in rows if r > BF16_GRAD_REL_L2]
+    assert not bad, bad[:10]

@@ -42,9 +42,9 @@ def canonical_to_oracle(name: str):
     return n
 
 
-def fill_hash_weights(model, dtype=torch.float32):
+def fill_hash_weights(model, dtype=torch.float32, overrides=None):
     """Load hash-generated parity weights through ``load_state_dict`` (exercises the q/k/v
-    split-merge and the alias keys)."""
+    split-merge and the alias keys).  ``overrides``: {canonical name: array} (oracle/cases.py weight_overrides)."""
     sd = model.state_dict()
     new = {}
     for k, v in sd.items():
@@ -57,7 +57,10 @@ def fill_hash_weights(model, dtype=torch.float32):
             n = "text_model.pooler." + n[len("text_pooler."):]
         elif n.startswith("vit_pooler."):
             n = "vit_model.pooler." + n[len("vit_pooler."):]
-        new[k] = torch.from_numpy(hashinit.param(n, tuple(v.shape))).to(v.dtype)
+        if overrides and n in overrides:
+            new[k] = torch.from_numpy(np.asarray(overrides[n]).reshape(tuple(v.shape)).copy()).to(v.dtype)
+        else:
+            new[k] = torch.from_numpy(hashinit.param(n, tuple(v.shape))).to(v.dtype)
     model.load_state_dict(new)
     return model
 
