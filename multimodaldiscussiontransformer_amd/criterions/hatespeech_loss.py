@@ -15,11 +15,11 @@ import torch
 
 from .. import ops
 from ..data.packer import packed_from_batched_data
-from ..registry import register_criterion
+from ..registry import FairseqCriterion, FairseqDataclass, register_criterion
 
 
 @dataclass
-class GraphPredictionNodeCrossEntropyConfig:
+class GraphPredictionNodeCrossEntropyConfig(FairseqDataclass):
     positive_weight: float = field(default=1.0, metadata={"help": "Weight to associate to the positive class"})
     negative_weight: float = field(default=1.0, metadata={"help": "Weight to associate to the negative class"})
 
@@ -39,12 +39,11 @@ class _NodeCE(torch.autograd.Function):
 
 
 @register_criterion("node_cross_entropy", dataclass=GraphPredictionNodeCrossEntropyConfig)
-class GraphPredictionNodeCrossEntropy(torch.nn.Module):
+class GraphPredictionNodeCrossEntropy(FairseqCriterion):
     """Node cross-entropy loss for graph node classification."""
 
     def __init__(self, task, positive_weight: float = 1.0, negative_weight: float = 1.0, fp16_loss: bool = True) -> None:
-        super().__init__()
-        self.task = task
+        super().__init__(task)
         self.positive_weight = float(positive_weight)
         self.negative_weight = float(negative_weight)
         self.fp16_loss = fp16_loss

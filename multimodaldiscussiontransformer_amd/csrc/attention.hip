@@ -556,9 +556,9 @@ static int dispatch_nt(hipStream_t st, const AttnParams& p) {
     if (p.f.drop_p > 0.f) return BWD ? launch_bwd<T, HD, N_, STRUCT, true>(st, p) : launch_fwd<T, HD, N_, STRUCT, true>(st, p); \
     return BWD ? launch_bwd<T, HD, N_, STRUCT, false>(st, p) : launch_fwd<T, HD, N_, STRUCT, false>(st, p);                    \
   }
-  ATT_CASE(2) ATT_CASE(5) ATT_CASE(7) ATT_CASE(9) ATT_CASE(13) ATT_CASE(16)
+  ATT_CASE(2) ATT_CASE(5) ATT_CASE(7) ATT_CASE(9) ATT_CASE(13) ATT_CASE(17)      // 17 tiles: ViT-L/14, 4 + 257 tokens
 #undef ATT_CASE
-  set_error("attention: S=%d exceeds the 256-token limit of the single-pass kernel", p.f.S);
+  set_error("attention: S=%d exceeds the 272-token limit of the single-pass kernel", p.f.S);
   return MDT_ERR_UNSUPPORTED;
 }
 

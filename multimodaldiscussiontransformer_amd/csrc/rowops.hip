@@ -210,6 +210,16 @@ __global__ void tanh_bwd_kernel(int64_t n, const T* y, const T* dy, T* dx) {
 // see fp16-rounded logits.
 __device__ __forceinline__ float round_f16(float v) { return (float)(_Float16)v; }
 
+// Arithmetic of the reference's loss on its CPU path, step by step (PyTorch's Half kernels round where they store):
+//   log_softmax (vec_log_softmax_lastdim, scalar_t = Half): the sum of exp(x - max) is stored as Half, so is its log,
+//     then out = half((x - max) - logsum);
+//   softmax for the predictions (vec_softmax_lastdim): exp and the sum stay in float, out = half(e * (1 / sum)) —
+//     two close logits can tie after the rounding, and argmax then returns index 0;
+//   nll_loss (nll_loss_out_frame, reduction "sum"): every term half(logp * w) is subtracted from Half partial sums
+//     cascaded in blocks of 16 (level_power = max(4, ceil(log2 n) / 8)), the 8 levels are added up in Half;
+//   backward: d logits = half(w * (exp(logp) - onehot)) (one rounding), cast back by the .type(HalfTensor) adjoint.
+// Checked against torch 2.10 CPU on random logits: bit-equal but for 1-ulp differences between expf / logf here and
+// sleef's there on knife-edge roundings (tests/test_kernels_gpu.py::test_node_ce_matches_torch_cpu_half).
 template <typename T>
 __global__ __launch_bounds__(256) void node_ce_kernel(int64_t M, int nlab, const T* logits, const int32_t* rows,
                                                       const int32_t* targets, float w_neg, float w_pos, int fp16_loss,
@@ -217,34 +227,79 @@ __global__ __launch_bounds__(256) void node_ce_kernel(int64_t M, int nlab, const
   // single workgroup: nlab is the number of labelled comments in the batch (tens to a few thousand)
   __shared__ float s_loss[256];
   __shared__ int s_cnt[4][256];
+  __shared__ float s_part[8];
   float loss = 0.f;
   int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-  for (int i = threadIdx.x; i < nlab; i += 256) {
-    const int64_t r = rows[i];
-    const int y = targets[i];
-    float l0 = to_f32(logits[r * 2]), l1 = to_f32(logits[r * 2 + 1]);
-    float wn = w_neg, wp = w_pos;
-    if (fp16_loss) { l0 = round_f16(l0); l1 = round_f16(l1); wn = round_f16(wn); wp = round_f16(wp); }
-    const float m = fmaxf(l0, l1);
-    const float lse = m + logf(expf(l0 - m) + expf(l1 - m));
-    float lp0 = l0 - lse, lp1 = l1 - lse;
-    if (fp16_loss) { lp0 = round_f16(lp0); lp1 = round_f16(lp1); }   // log_softmax output is a half tensor
-    const float w = y ? wp : wn;
-    loss += -w * (y ? lp1 : lp0);
-    const int pred = (l1 > l0) ? 1 : 0;          // argmax of softmax; ties -> index 0 like torch.argmax
-    c0 += (pred == y);
-    c1 += (pred == y && pred == 1);
-    c2 += (y == 1);
-    c3 += (pred == 1);
-    if (dlogits) {
-      // autograd differentiates through the (fp16-rounded) log-softmax output
-      const float p0 = expf(lp0), p1 = expf(lp1);
-      float g0 = w * (p0 - (y == 0 ? 1.f : 0.f)), g1 = w * (p1 - (y == 1 ? 1.f : 0.f));
-      if (fp16_loss) { g0 = round_f16(g0); g1 = round_f16(g1); }
-      dlogits[r * 2] = from_f32<T>(g0 * grad_scale);
-      dlogits[r * 2 + 1] = from_f32<T>(g1 * grad_scale);
+  int level_power = 4;
+  if (fp16_loss) {
+    int lg = 0;
+    while ((1ll << lg) < (long long)nlab) ++lg;          // ceil(log2(nlab))
+    if (lg / 8 > level_power) level_power = lg / 8;
+    if (threadIdx.x < 8) s_part[threadIdx.x] = 0.f;
+  }
+  for (int base = 0; base < nlab; base += 256) {
+    const int i = base + threadIdx.x;
+    float term = 0.f;
+    if (i < nlab) {
+      const int64_t r = rows[i];
+      const int y = targets[i];
+      float l0 = to_f32(logits[r * 2]), l1 = to_f32(logits[r * 2 + 1]);
+      float wn = w_neg, wp = w_pos;
+      if (fp16_loss) { l0 = round_f16(l0); l1 = round_f16(l1); wn = round_f16(wn); wp = round_f16(wp); }
+      const float m = fmaxf(l0, l1);
+      const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+      float lp0, lp1;
+      int pred;
+      if (fp16_loss) {
+        const float ls = round_f16(logf(round_f16(e0 + e1)));
+        lp0 = round_f16((l0 - m) - ls);
+        lp1 = round_f16((l1 - m) - ls);
+        const float inv = 1.0f / (e0 + e1);
+        pred = (round_f16(e1 * inv) > round_f16(e0 * inv)) ? 1 : 0;      // ties -> index 0 like torch.argmax
+      } else {
+        const float ls = logf(e0 + e1);
+        lp0 = (l0 - m) - ls;
+        lp1 = (l1 - m) - ls;
+        pred = (l1 > l0) ? 1 : 0;
+      }
+      const float w = y ? wp : wn;
+      term = w * (y ? lp1 : lp0);
+      if (fp16_loss) term = round_f16(term);
+      loss -= term;
+      c0 += (pred == y);
+      c1 += (pred == y && pred == 1);
+      c2 += (y == 1);
+      c3 += (pred == 1);
+      if (dlogits) {
+        // autograd differentiates through the (fp16-rounded) log-softmax output
+        const float p0 = expf(lp0), p1 = expf(lp1);
+        float g0 = w * (p0 - (y == 0 ? 1.f : 0.f)), g1 = w * (p1 - (y == 1 ? 1.f : 0.f));
+        if (fp16_loss) { g0 = round_f16(g0); g1 = round_f16(g1); }
+        dlogits[r * 2] = from_f32<T>(g0 * grad_scale);
+        dlogits[r * 2 + 1] = from_f32<T>(g1 * grad_scale);
+      }
+    }
+    if (fp16_loss) {
+      // the Half cascade is order-dependent: one thread walks this chunk's terms in label order
+      __syncthreads();
+      s_loss[threadIdx.x] = term;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int n = nlab - base < 256 ? nlab - base : 256;
+        const int lmask = (1 << level_power) - 1;
+        for (int k = 0; k < n; ++k) {
+          const int idx = base + k;
+          s_part[0] = round_f16(s_part[0] - s_loss[k]);
+          for (int j = 0; j + 1 < 8; ++j) {
+            if ((idx & (lmask << (j * level_power))) != 0) break;
+            s_part[j + 1] = round_f16(s_part[j + 1] + s_part[j]);
+            s_part[j] = 0.f;
+          }
+        }
+      }
     }
   }
+  __syncthreads();
   s_loss[threadIdx.x] = loss;
   s_cnt[0][threadIdx.x] = c0; s_cnt[1][threadIdx.x] = c1; s_cnt[2][threadIdx.x] = c2; s_cnt[3][threadIdx.x] = c3;
   __syncthreads();
@@ -252,7 +307,11 @@ __global__ __launch_bounds__(256) void node_ce_kernel(int64_t M, int nlab, const
     float L = 0.f;
     int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     for (int i = 0; i < 256; ++i) { L += s_loss[i]; a0 += s_cnt[0][i]; a1 += s_cnt[1][i]; a2 += s_cnt[2][i]; a3 += s_cnt[3][i]; }
-    out_loss[0] = fp16_loss ? round_f16(L) : L;
+    if (fp16_loss) {
+      L = 0.f;
+      for (int j = 0; j < 8; ++j) L = round_f16(L + s_part[j]);
+    }
+    out_loss[0] = L;
     counters[0] = a0; counters[1] = a1; counters[2] = a2; counters[3] = a3;
   }
 }

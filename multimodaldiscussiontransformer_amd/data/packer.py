@@ -187,6 +187,16 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
     )
     pb.ragged = ragged_text(ids, types, tmask, device=device, non_blocking=non_blocking)   # host-side: no device sync
     bd["_packed"] = pb                             # lets model(**net_input) find the CSR view
+    # the same view as plain tensors / ints: a sample that is moved between devices by a generic "apply to every tensor
+    # of the nested dict" (FairSeq's utils.move_to_cuda) carries these along, and packed_from_batched_data rebuilds the
+    # PackedBatch from them on the other side without any nonzero / host sync
+    rt = pb.ragged
+    bd["_csr"] = dict(
+        B=B, N=N, M=M, I=pb.I, L=Lq, n_labels=pb.n_labels, ids=pb.ids, types=pb.types, text_mask=pb.text_mask,
+        node_row=pb.node_row, graph_row=pb.graph_row, degree=pb.degree, deg_scatter=pb.deg_scatter, key_pad=pb.key_pad,
+        img_comment=pb.img_comment, label_rows=pb.label_rows, targets=pb.targets,
+        rt_rows=rt.rows, rt_max_len=rt.max_len, rt_offsets=rt.offsets, rt_ids=rt.ids, rt_types=rt.types, rt_pos=rt.pos,
+        rt_comment=rt.comment)
     return pb
 
 
@@ -200,8 +210,22 @@ def packed_from_batched_data(bd: dict) -> PackedBatch:
     """Compatibility path: derive the CSR view from a reference-style collated dict (as produced by
     ``collator``) that is already on the device.  Uses boolean-mask ``nonzero`` (one host sync);
     ``pack_batch`` avoids it by building the indices on the host."""
-    if "_packed" in bd:
+    dev_now = bd["x_token_mask"].device
+    if "_packed" in bd and bd["_packed"].ids.device == dev_now:
         return bd["_packed"]
+    if "_csr" in bd and bd["_csr"]["ids"].device == dev_now:
+        c = bd["_csr"]
+        images = bd.get("x_images")
+        pb = PackedBatch(
+            B=c["B"], N=c["N"], M=c["M"], I=c["I"], L=c["L"], batched_data=bd, ids=c["ids"], types=c["types"],
+            text_mask=c["text_mask"], node_row=c["node_row"], graph_row=c["graph_row"], degree=c["degree"],
+            deg_scatter=c["deg_scatter"], key_pad=c["key_pad"], attn_bias=bd["attn_bias"], spatial_pos=bd["spatial_pos"],
+            img_comment=c["img_comment"], images=images, label_rows=c["label_rows"], targets=c["targets"],
+            n_labels=c["n_labels"])
+        pb.ragged = RaggedText(rows=c["rt_rows"], max_len=c["rt_max_len"], offsets=c["rt_offsets"], ids=c["rt_ids"],
+                               types=c["rt_types"], pos=c["rt_pos"], comment=c["rt_comment"])
+        bd["_packed"] = pb
+        return pb
     mask = bd["x_token_mask"]
     dev = mask.device
     B, N = mask.shape

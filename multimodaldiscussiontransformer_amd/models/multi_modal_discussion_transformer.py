@@ -17,7 +17,7 @@ import torch.nn as nn
 from .. import engine as E
 from ..data.packer import packed_from_batched_data
 from ..modules import MultiGraphormerGraphEncoder, init_graphormer_params
-from ..registry import register_model, register_model_architecture
+from ..registry import FairseqEncoder, FairseqEncoderModel, register_model, register_model_architecture
 
 logger = logging.getLogger(__name__)
 
@@ -32,10 +32,11 @@ def safe_hasattr(obj, k):
 
 
 @register_model("multi_graphormer")
-class GraphormerModel(nn.Module):
+class GraphormerModel(FairseqEncoderModel):
+    """mDT/src/models/multi_modal_discussion_transformer.py:22-178 (extends FairseqEncoderModel there as here)."""
+
     def __init__(self, args, encoder):
-        super().__init__()
-        self.encoder = encoder
+        super().__init__(encoder)
         self.args = args
         if getattr(args, "apply_graphormer_init", False):
             self.apply(init_graphormer_params)
@@ -109,9 +110,9 @@ class GraphormerModel(nn.Module):
         self.main_grad_flat.zero_()
 
 
-class GraphormerEncoder(nn.Module):
+class GraphormerEncoder(FairseqEncoder):
     def __init__(self, args):
-        super().__init__()
+        super().__init__(dictionary=None)
         self.max_nodes = args.max_nodes
         extra = {}
         if getattr(args, "bert_config", None) is not None:

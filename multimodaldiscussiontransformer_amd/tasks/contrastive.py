@@ -1,6 +1,6 @@
-"""Task name ``contrastive_learning`` (mDT/src/tasks/contrastive.py:23): registered so launch
-scripts resolve; its criterion (community-contrastive BCE on the global embedding) is outside
-the accelerated path — the model already returns the global embedding it needs."""
+"""Task ``contrastive_learning`` (mDT/src/tasks/contrastive.py:23-48): community-contrastive pre-training on the
+global discussion embedding; batches carry ``hard_y`` beside ``y`` (data/dataset.py ContrastiveBatchedDataDataset),
+the criterion is ``contrastive_loss`` (criterions/contrastive_loss.py)."""
 from dataclasses import dataclass
 
 from ..registry import register_task
@@ -14,4 +14,8 @@ class ContrastiveLearningConfig(TaskConfig):
 
 @register_task("contrastive_learning", dataclass=ContrastiveLearningConfig)
 class ContrastiveLearningTask(Task):
-    pass
+    """Graph-level task: one community label (and one hard-negative community label) per discussion tree."""
+
+    def get_batched_dataset(self, dataset):
+        from ..data.dataset import ContrastiveBatchedDataDataset
+        return ContrastiveBatchedDataDataset(dataset, spatial_pos_max=self.cfg.spatial_pos_max)

@@ -475,6 +475,39 @@ def test_node_ce_matches_oracle(ops):
     torch.testing.assert_close(dl.cpu(), lr.grad, atol=1e-3, rtol=1e-3)
 
 
+@pytest.mark.parametrize("n,near_tie", [(7, False), (32, False), (33, True), (300, False), (1000, True), (2500, False)])
+def test_node_ce_matches_torch_cpu_half(ops, n, near_tie):
+    """The reference's loss runs in HALF precision whatever the model dtype (criterions/hatespeech_loss.py:58-64,95).
+    The kernel follows PyTorch's CPU Half kernels step by step (where they round: csrc/rowops.hip node_ce_kernel):
+    the loss VALUE (Half cascade sum), the counters (ties of the rounded softmax go to class 0) and d logits are
+    bit-equal to torch.nn.functional.cross_entropy on CPU half tensors, except where a 1-ulp difference between the
+    device's expf / logf and the host's lands on a rounding boundary (allowed: a few elements, one half-ulp each)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(100 + n)
+    M = n + 9
+    logits = torch.randn(M, 2, generator=g) * 1.5
+    if near_tie:                                             # margins far inside one half ulp
+        logits[:, 1] = logits[:, 0] + torch.randn(M, generator=g) * 2e-3
+    rows = torch.randperm(M, generator=g)[:n].sort().values
+    y = (torch.rand(n, generator=g) < 0.4).long()
+    lr = logits.clone().requires_grad_(True)
+    lh = lr[rows].type(torch.HalfTensor)
+    w = torch.tensor([1.0, 1.5]).type(torch.HalfTensor)
+    pred = torch.argmax(F.softmax(lh, dim=-1), dim=-1)
+    loss = F.cross_entropy(lh, y, reduction="sum", weight=w)
+    loss.backward()
+    l, c, dl = ops.node_ce(dev(logits), dev(rows.int()), dev(y.int()), 1.0, 1.5)
+    want = [int((pred == y).sum()), int(((pred == y) & (pred == 1)).sum()), int((y == 1).sum()), int((pred == 1).sum())]
+    got = c.cpu().tolist()
+    assert got[2] == want[2]
+    assert max(abs(a - b) for a, b in zip(got, want)) <= (2 if near_tie else 0), (got, want)
+    ulp = 2.0 ** (max(-14, int(np.floor(np.log2(max(abs(float(loss)), 1e-6))))) - 10)
+    assert abs(float(l.cpu()) - float(loss)) <= ulp, (float(l.cpu()), float(loss))      # within one Half ulp (usually equal)
+    d = (dl.cpu() - lr.grad).abs()
+    assert float(d.max()) <= 2.0 ** -10                                                   # one half-ulp step of a value < 2
+    assert int((d > 0).sum()) <= max(2, n // 50), int((d > 0).sum())
+
+
 # ----------------------------------------------------------------------------- ragged attention
 @pytest.mark.parametrize("dtype,bwd", [(torch.float32, None), (torch.bfloat16, None), (torch.bfloat16, "v1"), (torch.bfloat16, "v2")])
 @pytest.mark.parametrize("Smax,H", [(40, 2), (104, 3), (201, 2)])

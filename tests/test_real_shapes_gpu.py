@@ -162,8 +162,9 @@ def test_bf16_real_shapes_vs_fp32_oracle(kind):
         gr = split_qkv_grad(name, grads)
         assert gr is not None, name
         rn = float(ref.double().norm())
-        if rn < 1e-7:
-            assert float(gr.float().norm()) < 1e-4, name
+        if rn < 1e-6:
+            # mathematically zero (a key bias shifts every score of a row alike): what is left is rounding noise
+            assert float(gr.float().norm()) < 5e-3, name
             continue
         rel = float((gr.float().cpu().double() - ref.double()).norm()) / rn
         rows.append((rel, name, rn, ref.numel()))
