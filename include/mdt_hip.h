@@ -226,6 +226,19 @@ int mdt_node_ce(void* stream, int dtype, int64_t M, int nlab, const void* logits
                 const int32_t* targets, float w_neg, float w_pos, int fp16_loss, float grad_scale,
                 float* out_loss, int32_t* counters, void* dlogits);
 
+/* Community-contrastive loss on the global discussion embeddings (criterions/contrastive_loss.py:76-180):
+ * emb T[B, D] (row stride ld), y / hard_y f32[B] (community label of every tree and of its polar-opposite community);
+ * sim = scale * normalize(emb) normalize(emb)^T, weighted BCE against [y_i == y_j] with the reference's soft-negative
+ * weights (adaptive != 0: 2 * #hard / #soft per row, applied along the LAST axis as the reference's broadcast does;
+ * otherwise soft_negative_weight), diagonal excluded.  out_loss f32[1] (sum over the B x B pairs), counters i32[4] =
+ * ncorrect, positive_correct, total_positive, pred_positive as the reference defines them (:153-161);
+ * d_emb T[B, D] = grad_scale * dL/d emb (NULL: forward only).  workspace: mdt_contrastive_loss_workspace_bytes(B, D)
+ * bytes owned by the caller. */
+size_t mdt_contrastive_loss_workspace_bytes(int B, int D);
+int mdt_contrastive_loss(void* stream, int dtype, int B, int D, const void* emb, int64_t ld, const float* y,
+                         const float* hard_y, float scale, float soft_negative_weight, int adaptive, void* workspace,
+                         float grad_scale, float* out_loss, int32_t* counters, void* d_emb, int64_t ldd);
+
 /* Elementwise cast / transpose helpers for the bf16 weight shadow copies. */
 int mdt_cast(void* stream, int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst);
 int mdt_transpose2d(void* stream, int src_dtype, int dst_dtype, int64_t rows, int64_t cols,

@@ -64,6 +64,8 @@ _SIGS = {
     "mdt_tanh_fwd": ([_vp, _i, _i64, _vp, _vp], _i),
     "mdt_tanh_bwd": ([_vp, _i, _i64, _vp, _vp, _vp], _i),
     "mdt_node_ce": ([_vp, _i, _i64, _i, _vp, _vp, _vp, _f, _f, _i, _f, _vp, _vp, _vp], _i),
+    "mdt_contrastive_loss_workspace_bytes": ([_i, _i], C.c_size_t),
+    "mdt_contrastive_loss": ([_vp, _i, _i, _i, _vp, _i64, _vp, _vp, _f, _f, _i, _vp, _f, _vp, _vp, _vp, _i64], _i),
     "mdt_adam_step_multi": ([_vp, _i, _i, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp], _i),
     "mdt_cast": ([_vp, _i, _i, _i64, _vp, _vp], _i),
     "mdt_transpose2d": ([_vp, _i, _i, _i64, _i64, _vp, _i64, _vp, _i64], _i),

@@ -90,13 +90,13 @@ class GraphPredictionNodeCrossEntropy(FairseqCriterion):
         fairseq is installed, otherwise keeps the values in ``last_metrics``."""
         m = GraphPredictionNodeCrossEntropy.compute_metrics(logging_outputs)
         GraphPredictionNodeCrossEntropy.last_metrics = m
-        try:  # pragma: no cover
+        try:
             from fairseq import metrics
-            sample_size = sum(float(log.get("sample_size", 0)) for log in logging_outputs)
-            for k, v in m.items():
-                metrics.log_scalar(k, v, sample_size, round=3)
-        except Exception:  # noqa: BLE001
-            pass
+        except ImportError:
+            return
+        sample_size = sum(float(log.get("sample_size", 0)) for log in logging_outputs)
+        for k, v in m.items():
+            metrics.log_scalar(k, v, sample_size, round=3)
 
     @staticmethod
     def logging_outputs_can_be_summed() -> bool:

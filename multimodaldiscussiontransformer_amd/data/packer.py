@@ -142,8 +142,9 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
         img_index.append(np.asarray(t["image_index"], dtype=bool))
         if t["images"] is not None and len(t["images"]):
             images.append(torch.from_numpy(np.ascontiguousarray(t["images"], dtype=np.float32)))
-        ys.append(np.asarray(t["y"], dtype=np.float32))
-        y_masks.append(np.asarray(t["y_mask"], dtype=bool))
+        ys.append(np.asarray(t["y"], dtype=np.float32).reshape(-1))
+        # node task: which comments carry a label; graph-level (contrastive) trees have one y per tree and no mask
+        y_masks.append(np.asarray(t["y_mask"], dtype=bool) if "y_mask" in t else np.zeros(n, dtype=bool))
         m += n
     token_mask = ~(x == 0).all(dim=2)                      # collator.py:141
     if not bool(torch.equal(token_mask.sum(1), torch.tensor(n_nodes))):
@@ -151,6 +152,9 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
     img_index = np.concatenate(img_index)
     y = np.concatenate(ys)
     y_mask = np.concatenate(y_masks)
+    node_task = "y_mask" in trees[0]
+    if node_task and int(y_mask.sum()) != y.shape[0]:
+        raise ValueError("y must hold exactly one entry per True in y_mask")
     img_comment = torch.from_numpy(np.nonzero(img_index)[0].astype(np.int32))
     label_rows = torch.from_numpy(np.nonzero(y_mask)[0].astype(np.int32))
     images_t = torch.cat(images) if images else None
@@ -175,15 +179,19 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
         x_images=to(images_t),
         x_image_indexes=to(torch.from_numpy(img_index)),
         y=to(torch.from_numpy(y)),
-        y_mask=to(torch.from_numpy(y_mask)),
     )
+    if node_task:
+        bd["y_mask"] = to(torch.from_numpy(y_mask))
+    if "hard_y" in trees[0]:
+        bd["hard_y"] = to(torch.from_numpy(np.concatenate([np.asarray(t["hard_y"], dtype=np.float32).reshape(-1) for t in trees])))
     bd["out_degree"] = bd["in_degree"]            # collator.py:171 — the same tensor object
     pb = PackedBatch(
         B=B, N=N, M=M, I=int(img_comment.numel()), L=Lq, batched_data=bd,
         ids=to(ids), types=to(types), text_mask=to(tmask), node_row=to(node_row), graph_row=to(graph_row),
         degree=to(in_deg_t.reshape(-1).int()), deg_scatter=to(deg_scatter.view(-1)), key_pad=to(key_pad), attn_bias=bd["attn_bias"],
         spatial_pos=bd["spatial_pos"], img_comment=to(img_comment), images=bd["x_images"],
-        label_rows=to(label_rows), targets=to(torch.from_numpy(y.astype(np.int32))), n_labels=int(label_rows.numel()),
+        label_rows=to(label_rows), targets=to(torch.from_numpy((y if node_task else y[:0]).astype(np.int32))),
+        n_labels=int(label_rows.numel()),
     )
     pb.ragged = ragged_text(ids, types, tmask, device=device, non_blocking=non_blocking)   # host-side: no device sync
     bd["_packed"] = pb                             # lets model(**net_input) find the CSR view

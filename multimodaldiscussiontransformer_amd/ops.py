@@ -18,7 +18,7 @@ __all__ = [
     "bert_embed_rows",
     "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "graph_attn_bias",
     "row_axpby", "row_scatter_add", "bert_embed_sum", "vit_patchify", "vit_assemble", "graph_node_feature",
-    "tanh_fwd", "tanh_bwd", "node_ce", "cast", "transpose2d", "dropout", "dropout_mask",
+    "tanh_fwd", "tanh_bwd", "node_ce", "contrastive_loss", "cast", "transpose2d", "dropout", "dropout_mask",
     "EPI_BIAS", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_ACCUM", "EPI_ATOMIC", "EPI_DROPOUT", "EPI_AUX_GRAD", "EPI_MULAUX",
 ]
 
@@ -267,6 +267,20 @@ def node_ce(logits, rows, targets, w_neg, w_pos, *, fp16_loss=True, grad_scale=1
                           float(w_pos), int(fp16_loss), float(grad_scale), ptr(loss), ptr(counters), ptr(dlogits)),
           "mdt_node_ce")
     return loss, counters, dlogits
+
+
+def contrastive_loss(emb, y, hard_y, scale, soft_negative_weight, adaptive, *, grad_scale=1.0, want_grad=True):
+    """emb [B, D] (row-major), y / hard_y f32[B] → (loss f32[1], counters i32[4], d_emb or None); include/mdt_hip.h."""
+    B, D = emb.shape
+    assert y.dtype == torch.float32 and hard_y.dtype == torch.float32 and y.numel() == B and hard_y.numel() == B
+    ws = torch.empty(lib.mdt_contrastive_loss_workspace_bytes(B, D), dtype=torch.uint8, device=emb.device)
+    loss = torch.empty(1, dtype=torch.float32, device=emb.device)
+    counters = torch.empty(4, dtype=torch.int32, device=emb.device)
+    d_emb = torch.empty_like(emb) if want_grad else None
+    check(lib.mdt_contrastive_loss(stream(), dt(emb), B, D, ptr(emb), _2d(emb), ptr(y), ptr(hard_y), float(scale),
+                                   float(soft_negative_weight), int(bool(adaptive)), ptr(ws), float(grad_scale), ptr(loss),
+                                   ptr(counters), ptr(d_emb), _2d(d_emb) if d_emb is not None else 0), "mdt_contrastive_loss")
+    return loss, counters, d_emb
 
 
 def cast(src, dtype):

@@ -120,3 +120,30 @@ def weight_overrides(kind):
     if s is None:
         return {}
     return {"node_classifier.bias": np.asarray([s / 2.0, -s / 2.0], dtype=np.float32)}
+
+
+# ----------------------------------------------------------------------------- contrastive cases
+def contrastive_labels(n_trees, kind="A"):
+    """(y, hard_y) community labels per tree.  Community 1 exists so that ``total_positive`` and the reference's
+    ``pred == targets`` counters are non-trivial; every tree has at least one soft-negative partner (no 0 / 0)."""
+    if kind == "A":          # 12 trees, 4 communities
+        y = np.asarray([0, 1, 2, 3, 0, 1, 2, 3, 1, 0, 3, 2][:n_trees], dtype=np.float32)
+        hard = np.asarray([1, 0, 3, 2, 1, 0, 3, 2, 0, 1, 2, 3][:n_trees], dtype=np.float32)
+    else:                    # 5 trees, 3 communities (full-model case)
+        y = np.asarray([1, 0, 2, 1, 0][:n_trees], dtype=np.float32)
+        hard = np.asarray([0, 1, 0, 2, 2][:n_trees], dtype=np.float32)
+    return y, hard
+
+
+def contrastive_trees(hp):
+    """5 small trees (tiny "A" shapes, one with images) labelled per TREE for the contrastive task."""
+    rng = np.random.Generator(np.random.PCG64(808))
+    spec = ((6, 0.34, "bushy"), (4, 0.0, "deep"), (7, 0.0, "bushy"), (3, 0.34, "deep"), (5, 0.0, "bushy"))
+    trees = [synthetic.make_tree(n, rng, seq_len=16, vocab_size=hp.vocab_size, image_frac=f, image_size=hp.image_size,
+                                 shape=s, min_len=3) for n, f, s in spec]
+    y, hard = contrastive_labels(len(trees), "B")
+    for i, t in enumerate(trees):
+        t.pop("y_mask")
+        t["y"] = np.asarray([y[i]], dtype=np.float32)
+        t["hard_y"] = np.asarray([hard[i]], dtype=np.float32)
+    return trees

@@ -136,6 +136,8 @@ def mount_reference():
     pre = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(pre)
     loss = importlib.import_module("src.criterions.hatespeech_loss")
+    global CONTRASTIVE_MOD
+    CONTRASTIVE_MOD = importlib.import_module("src.criterions.contrastive_loss")
     return mods, models, collator, pre, loss
 
 
@@ -484,6 +486,71 @@ def case_full_model(mods, models, collator_mod, pre, updown, loss_mod, metrics, 
               "n", sample_size, flush=True)
 
 
+def case_contrastive(mods, models, collator_mod, pre, updown):
+    """criterions/contrastive_loss.py (the REAL criterion) — (a) on hash-generated embeddings through a stub model, all
+    three weighting modes; (b) end to end: the reference encoder on 5 small trees, which gives the final graph stack
+    (gradient-free under node_cross_entropy) a gradient."""
+    cl = CONTRASTIVE_MOD
+    out = {}
+    B, D = 12, 768
+    y, hard = cases.contrastive_labels(B, "A")
+    emb0 = hashinit.uniform("cl/emb", (B, D), 1.0)
+    emb0[:, :64] += np.asarray(y)[:, None] * 0.35            # communities are partly separable: mixed predictions
+    for tag, kw in (("adaptive", dict(soft_negative_weight=0.0, multiplication_scale=20.0, adaptive_soft_negative_weight=True)),
+                    ("fixed", dict(soft_negative_weight=0.25, multiplication_scale=20.0, adaptive_soft_negative_weight=False)),
+                    ("strict", dict(soft_negative_weight=0.0, multiplication_scale=1.0, adaptive_soft_negative_weight=False))):
+        emb = torch.from_numpy(emb0.copy()).requires_grad_(True)
+        crit = cl.GraphContrastiveLoss(task=None, **kw)
+        stub = lambda batched_data, e=emb: (None, e)
+        sample = {"net_input": {"batched_data": {"x": torch.zeros(B, 7, 3), "y": torch.from_numpy(y), "hard_y": torch.from_numpy(hard)}}}
+        lossv, n, log = crit(stub, sample)
+        lossv.backward()
+        out[f"{tag}/loss"] = np_(lossv)
+        out[f"{tag}/sample_size"] = np.asarray(n)
+        out[f"{tag}/d_emb"] = np_(emb.grad)
+        for k in ("ncorrect", "positive_correct", "total_positive", "pred_positive"):
+            out[f"{tag}/{k}"] = np.asarray(int(log[k]))
+        print("contrastive", tag, float(lossv), {k: int(log[k]) for k in ("ncorrect", "positive_correct", "total_positive", "pred_positive")})
+    out["emb"] = emb0
+    out["y"], out["hard_y"] = y, hard
+    # (b) full model
+    hp = tiny_hparams("A")
+    trees = cases.contrastive_trees(hp)
+    for t in trees:
+        t["y_mask"] = np.zeros(len(t["parent"]), dtype=bool)      # ref_items_from_trees reads it; unused by this task
+    items = ref_items_from_trees(trees, pre, updown)
+    batch = ref_collate(items, collator_mod, 5)
+    del batch["y_mask"]
+    batch["hard_y"] = torch.cat([torch.from_numpy(t["hard_y"]) for t in trees])
+    enc = build_reference_encoder(mods, hp)
+    genc = models.GraphormerEncoder.__new__(models.GraphormerEncoder)
+    nn.Module.__init__(genc)
+    genc.graph_encoder = enc
+    genc.node_encoder_stack = nn.ModuleList([enc.text_pooler, enc.text_dropout, enc.node_classifier])
+    model = models.GraphormerModel.__new__(models.GraphormerModel)
+    nn.Module.__init__(model)
+    model.encoder = genc
+    model.train()
+    named = fill_params(enc)
+    crit = cl.GraphContrastiveLoss(task=None, soft_negative_weight=0.0, multiplication_scale=20.0, adaptive_soft_negative_weight=True)
+    lossv, n, log = crit(model, {"net_input": {"batched_data": batch}})
+    lossv.backward()
+    _, glob = model(batch)
+    out["full/loss"] = np_(lossv)
+    out["full/sample_size"] = np.asarray(n)
+    out["full/global"] = np_(glob)
+    for k in ("ncorrect", "positive_correct", "total_positive", "pred_positive"):
+        out[f"full/{k}"] = np.asarray(int(log[k]))
+    gs = {}
+    grad_summary(named, gs)
+    for k, v in gs.items():
+        out["full/" + k] = v
+    out["full/n_trainable_with_grad"] = np.asarray(sum(1 for p in named.values() if p.grad is not None))
+    print("contrastive full", float(lossv), int(out["full/n_trainable_with_grad"]),
+          "final stack |g|", float(gs["gnorm/layers.2.layers.0.fc1.weight"]))
+    np.savez_compressed(os.path.join(OUT, "contrastive.npz"), **out)
+
+
 def case_fusion_layer(mods):
     from transformers import BertConfig, ViTConfig
     from transformers.models.bert.modeling_bert import BertLayer
@@ -540,6 +607,9 @@ def main():
     metrics = install_fairseq_standins()
     mods, models, collator_mod, pre, loss_mod = mount_reference()
     updown = load_updown_functions()
+    if only and only[0] == "contrastive":
+        case_contrastive(mods, models, collator_mod, pre, updown)
+        return
     if only and only[0].startswith("full:"):
         case_full_model(mods, models, collator_mod, pre, updown, loss_mod, metrics, kinds=tuple(only[0][5:].split(",")))
         return
@@ -551,6 +621,8 @@ def main():
     print("fusion layer done")
     case_full_model(mods, models, collator_mod, pre, updown, loss_mod, metrics)
     print("full model done")
+    case_contrastive(mods, models, collator_mod, pre, updown)
+    print("contrastive done")
 
 
 if __name__ == "__main__":

@@ -390,6 +390,34 @@ def node_cross_entropy(logits_all, y, y_mask, hp):
     return loss, counters
 
 
+def contrastive_loss(embeddings, y, hard_y, scale=20.0, soft_negative_weight=0.0, adaptive=True):
+    """criterions/contrastive_loss.py:76-180 on CPU tensors: → (loss, counters).  The broadcasts are the reference's:
+    ``extra_weight`` [B] and ``targets`` [B] act along the LAST axis of the [B, B] matrices (:143-147, :155)."""
+    nA = F.normalize(embeddings, p=2, dim=1)
+    sim = (torch.mm(nA, nA.transpose(0, 1)) * scale).float()
+    targets = y.float()
+    # .half() as in the reference (:122, :126): binary_cross_entropy_with_logits then runs its in-place chain on a
+    # HALF tensor (every step rounds to half, the loss value is a half) and autograd returns half(weight) * (sigmoid - t)
+    target_matrix = targets.unsqueeze(1).eq(targets).half()
+    hard_matrix = hard_y.float().unsqueeze(1).eq(targets).half()
+    soft_labels = torch.logical_and(target_matrix.eq(0), hard_matrix.eq(0))
+    if adaptive:
+        num_hard = torch.logical_or(target_matrix.eq(1), hard_matrix.eq(1)).sum(dim=1)
+        extra = (num_hard / soft_labels.sum(dim=1)) * 2
+    else:
+        extra = soft_negative_weight
+    soft_matrix = torch.where(soft_labels, extra, 1)
+    soft_matrix = torch.where(torch.eye(soft_matrix.size(0)).eq(1), 0, soft_matrix)
+    with torch.no_grad():
+        pred = torch.sigmoid(sim).round()
+        counters = dict(ncorrect=int((pred == targets).sum()),
+                        positive_correct=int(torch.logical_and(pred == targets, pred == 1).sum()),
+                        total_positive=int((targets == 1).sum()), pred_positive=int((pred == 1).sum()),
+                        sample_size=int(sim.shape[0] * sim.shape[1]))
+    loss = F.binary_cross_entropy_with_logits(sim, target_matrix, weight=soft_matrix, reduction="sum").float()
+    return loss, counters
+
+
 def f1_metrics(c: dict) -> dict:
     """hatespeech_loss.py:133-173 (zero guards included)."""
     tp, totp, predp, n = (c["num_positive_correct"], c["total_positive"],

@@ -206,3 +206,52 @@ def test_full_model(golden_dir, kind):
         assert abs(float(mine.norm()) - gn) <= 1e-3 * max(1e-3, gn) + 1e-6, (n, float(mine.norm()), gn)
         np.testing.assert_allclose(mine[:64].float().numpy(), g["gslice/" + n], atol=1e-3 * max(1.0, gn))
     assert n_with == int(g["n_trainable_with_grad"])
+
+
+def test_contrastive_loss(golden_dir):
+    """oracle.contrastive_loss against the REAL reference criterion (criterions/contrastive_loss.py) on hash-generated
+    embeddings: loss (a half value in the reference: equal), counters (equal) and d loss / d embeddings."""
+    g = _load(golden_dir, "contrastive.npz")
+    y, hard = torch.from_numpy(g["y"]), torch.from_numpy(g["hard_y"])
+    for tag, kw in (("adaptive", dict(scale=20.0, soft_negative_weight=0.0, adaptive=True)),
+                    ("fixed", dict(scale=20.0, soft_negative_weight=0.25, adaptive=False)),
+                    ("strict", dict(scale=1.0, soft_negative_weight=0.0, adaptive=False))):
+        emb = torch.from_numpy(g["emb"].copy()).requires_grad_(True)
+        loss, c = R.contrastive_loss(emb, y, hard, **kw)
+        loss.backward()
+        assert float(loss) == float(g[f"{tag}/loss"]), tag
+        assert c["sample_size"] == int(g[f"{tag}/sample_size"])
+        for k in ("ncorrect", "positive_correct", "total_positive", "pred_positive"):
+            assert c[k] == int(g[f"{tag}/{k}"]), (tag, k)
+        np.testing.assert_allclose(emb.grad.numpy(), g[f"{tag}/d_emb"], atol=1e-6, rtol=1e-5)
+    assert int(g["adaptive/pred_positive"]) not in (0, 144) and int(g["adaptive/ncorrect"]) > 0
+
+
+def test_contrastive_full_model(golden_dir):
+    """End to end under the contrastive objective: the oracle's encoder → global embedding → contrastive loss against
+    the reference run; the FINAL graph stack (gradient-free under node_cross_entropy, quirk 3) has a gradient here."""
+    g = _load(golden_dir, "contrastive.npz")
+    hp = cases.tiny_hparams("A")
+    trees = cases.contrastive_trees(hp)
+    batch = R.to_torch_batch(S.collate(trees, 5))
+    W = R.make_weights(hp)
+    _, _, glob = R.encoder_forward(W, hp, batch)
+    np.testing.assert_allclose(glob.detach().numpy(), g["full/global"], atol=1e-4)
+    loss, c = R.contrastive_loss(glob, batch["y"], batch["hard_y"])
+    assert abs(float(loss) - float(g["full/loss"])) <= 0.5 + 1e-3 * abs(float(g["full/loss"]))      # a half value: ulp 0.5 at ~900
+    for k in ("ncorrect", "positive_correct", "total_positive", "pred_positive"):
+        assert c[k] == int(g[f"full/{k}"]), k
+    loss.backward()
+    n_with = 0
+    for n in R.param_shapes(hp):
+        gn = float(g["full/gnorm/" + n])
+        if gn < 0:
+            assert W[n].grad is None or float(W[n].grad.abs().max()) == 0.0, n
+            continue
+        n_with += 1
+        mine = W[n].grad.double().flatten()
+        assert abs(float(mine.norm()) - gn) <= 1e-3 * max(1e-3, gn) + 1e-6, (n, float(mine.norm()), gn)
+        np.testing.assert_allclose(mine[:64].float().numpy(), g["full/gslice/" + n], atol=1e-3 * max(1.0, gn))
+    assert n_with == int(g["full/n_trainable_with_grad"])
+    assert float(g["full/gnorm/layers.2.layers.0.fc1.weight"]) > 0          # the final graph stack trains
+    assert float(g["full/gnorm/node_classifier.weight"]) < 0                # the classifier head does not
