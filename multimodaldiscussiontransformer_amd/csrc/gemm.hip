@@ -934,19 +934,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
     Desc d;
     d.m0 = (int64_t)tm * BM;
     d.n0 = (int64_t)tn * BN;
+    // diagnostic (MDT_GEMM_DIAG=8): every tile LOADS the operand panels of tile (0, 0) — all fills hit L2 — while
+    // stores still go to the tile's own place: separates the fill's miss path from the loop's own cost
+    const int64_t lm0 = (p.epilogue & (1 << 23)) ? 0 : d.m0, ln0 = (p.epilogue & (1 << 23)) ? 0 : d.n0;
     const char* a_base;
     const char* b_base;
     int64_t a_bytes, b_bytes;
-    if constexpr (!A_KM) { a_base = (const char*)p.A + d.m0 * lda_b; a_bytes = (p.M - d.m0) * lda_b; }
+    if constexpr (!A_KM) { a_base = (const char*)p.A + lm0 * lda_b; a_bytes = (p.M - lm0) * lda_b; }
     else { a_base = (const char*)p.A; a_bytes = p.K * lda_b; }
-    if constexpr (!B_KM) { b_base = (const char*)p.B + d.n0 * ldb_b; b_bytes = (p.N - d.n0) * ldb_b; }
+    if constexpr (!B_KM) { b_base = (const char*)p.B + ln0 * ldb_b; b_bytes = (p.N - ln0) * ldb_b; }
     else { b_base = (const char*)p.B; b_bytes = p.K * ldb_b; }
     const unsigned a_rec = (unsigned)(a_bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : a_bytes);
     const unsigned b_rec = (unsigned)(b_bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : b_bytes);
     d.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, a_rec, 0x00020000);
     d.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, b_rec, 0x00020000);
-    d.a_col0 = A_KM ? (int)d.m0 : 0;
-    d.b_col0 = B_KM ? (int)d.n0 : 0;
+    d.a_col0 = A_KM ? (int)lm0 : 0;
+    d.b_col0 = B_KM ? (int)ln0 : 0;
     return d;
   };
   auto issue_step = [&](const Desc& d, int hs, int buf) {

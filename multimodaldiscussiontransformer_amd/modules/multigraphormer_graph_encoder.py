@@ -245,9 +245,19 @@ class MultiGraphormerGraphEncoder(nn.Module):
             tape.enable_side(pb.ids.device)
         # the 6 + 6 pre-fusion layers of the two modalities are independent: image branch first (on the side stream of
         # a two-stream tape), text branch beside it
+        # --freeze_initial_encoders (the reference launch, run_train.sh:61): autograd stops at the frozen stacks there.
+        # A prefix without any trainable parameter records no adjoint (nothing of it is kept for backward) and its
+        # output is a constant of the tape, so the gradient chain ends at the first fusion layer.
+        def trainable(*mods):
+            return any(p.requires_grad for m in mods for p in m.parameters())
+
+        vit_live = trainable(vm.embeddings, vm.encoder, vm.layernorm)
+        text_live = trainable(tm.embeddings, tm.encoder)
+        was_inference = tape.inference
         vit = None
         if I > 0:
             tape.fork()
+            tape.inference = was_inference or not vit_live
             with tape.on_side():
                 ve = vm.embeddings
                 v = E.vit_embeddings(tape, pb.images, ve.patch_embeddings.projection.weight, ve.patch_embeddings.projection.bias,
@@ -258,7 +268,9 @@ class MultiGraphormerGraphEncoder(nn.Module):
                     v = E.transformer_block(tape, v, layer.block_params(), specv, pre_ln=True, eps=vm.eps,
                                             **layer.drop_kwargs())
                 v = E.layernorm(tape, v, vm.layernorm.weight, vm.layernorm.bias, vm.eps)      # quirk 5: final LN mid-network
-                vit = E.expand_sequences(tape, v, I, P, nb, None)
+                v.needs_grad = vit_live
+                vit = E.expand_sequences(tape, v, I, P, nb, None)     # zero bottleneck rows in front: no parameter involved
+        tape.inference = was_inference or not text_live
         e = tm.embeddings
         if ix["ragged"]:
             rt = get_ragged(pb)
@@ -272,6 +284,8 @@ class MultiGraphormerGraphEncoder(nn.Module):
         for layer in tm.encoder.layer:
             text = E.transformer_block(tape, text, layer.block_params(), spec0, pre_ln=False, eps=tm.eps,
                                        **layer.drop_kwargs())
+        text.needs_grad = text_live
+        tape.inference = was_inference
         if I > 0:
             tape.join()
         text = E.expand_rows(tape, text, ix["rows_fus"], ix["pre2fus"], ix["bn_rows_all"], nb, self.bottle_neck.weight)

@@ -95,6 +95,16 @@ class PolynomialDecayLR:
     def __init__(self, lr=3e-5, end_lr=3e-7, warmup_updates=3246, total_num_update=10820, power=1.0):
         self.lr, self.end_lr, self.warmup, self.total, self.power = lr, end_lr, warmup_updates, total_num_update, power
 
+    def for_update(self, k: int) -> float:
+        """Learning rate update ``k`` (1-based) RUNS with under FairSeq's trainer.  FairSeq calls
+        ``lr_scheduler.step_update(num_updates)`` after an update, so update k uses the rate of ``num_updates = k - 1``;
+        before the first update the scheduler's constructor has set ``warmup_factor * lr`` with warmup_factor =
+        1 / warmup_updates (fairseq/optim/lr_scheduler/polynomial_decay_schedule.py: __init__ and step_update)."""
+        done = k - 1
+        if done <= 0:
+            return self.lr / self.warmup if self.warmup > 0 else self.lr
+        return self(done)
+
     def __call__(self, num_updates: int) -> float:
         if self.warmup > 0 and num_updates <= self.warmup:
             return self.lr * num_updates / float(self.warmup)

@@ -48,6 +48,7 @@ class Task(FairseqTask):
         super().__init__(cfg)
         from ..data.dataset import GraphormerDataset
         self.dm = None
+        self.collate_device = "cpu"        # DataLoader workers collate on the host; train.py collates straight to the GPU
         if cfg.user_data_dir != "":
             self._import_user_defined_datasets(cfg.user_data_dir)
             if cfg.dataset_name not in DATASET_REGISTRY:

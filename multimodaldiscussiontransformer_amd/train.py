@@ -58,10 +58,31 @@ def build_parser():
     p.add_argument("--fp16", action="store_true", default=False, help="the reference's half precision; runs as bf16 here")
     p.add_argument("--bf16", action="store_true", default=False)
     p.add_argument("--log-interval", type=int, default=10)
-    p.add_argument("--positive-weight", type=float, default=1.0)
-    p.add_argument("--negative-weight", type=float, default=1.0)
+    # criterion flags: every field of every registered criterion's config dataclass (FairSeq derives them the same way)
+    from .registry import CRITERION_REGISTRY as _CR
+    for _cls, _dc in _CR.values():
+        for f in getattr(_dc, "__dataclass_fields__", {}).values():
+            if f.name.startswith("_"):
+                continue
+            flag = "--" + f.name.replace("_", "-")
+            if f.type in (bool, "bool"):
+                p.add_argument(flag, type=lambda v: str(v).lower() in ("1", "true", "yes"), nargs="?", const=True, default=f.default)
+            else:
+                p.add_argument(flag, type=type(f.default), default=f.default)
     p.add_argument("--distributed-world-size", type=int, default=1)
-    p.add_argument("--save-checkpoint", default="", help="write model.state_dict() (reference key names) here at the end")
+    p.add_argument("--save-checkpoint", default="", help="write a FairSeq-layout checkpoint here at the end")
+    p.add_argument("--save-dir", default="", help="FairSeq: checkpoint_last.pt (and checkpoint<epoch>.pt) are written here")
+    p.add_argument("--save-interval-updates", type=int, default=0)
+    p.add_argument("--no-save", action="store_true", default=False)
+    p.add_argument("--restore-file", default="", help="FairSeq checkpoint to start from (run_train.sh:58)")
+    p.add_argument("--reset-optimizer", action="store_true", default=False)
+    p.add_argument("--reset-lr-scheduler", action="store_true", default=False)
+    p.add_argument("--reset-meters", action="store_true", default=False)
+    p.add_argument("--reset-dataloader", action="store_true", default=False)
+    p.add_argument("--clip-norm", type=float, default=0.0)
+    p.add_argument("--required-batch-size-multiple", type=int, default=1)
+    p.add_argument("--validate-interval-updates", type=int, default=0)
+    p.add_argument("--wandb-project", default=None)
     # synthetic data controls
     p.add_argument("--synthetic-nodes", type=int, default=16)
     p.add_argument("--synthetic-seq-len", type=int, default=32)
@@ -102,7 +123,13 @@ def main(argv=None):
     parser = build_parser()
     args, unknown = parser.parse_known_args(argv)
     if unknown:
-        print(f"[mdt-train] ignoring FairSeq flags outside the accelerated path: {' '.join(unknown)}", file=sys.stderr)
+        # a flag this launcher does not know may change what is trained: refuse instead of training something else
+        raise SystemExit(f"[mdt-train] unsupported FairSeq flag(s): {' '.join(unknown)} — this launcher implements the flags of "
+                         "mDT/experiments/hateful_discussions/run_train.sh; run fairseq-train --user-dir <repo>/src for the rest")
+    if args.clip_norm and args.clip_norm > 0:
+        raise SystemExit("[mdt-train] --clip-norm is not implemented (the reference launch does not use it)")
+    if args.wandb_project:
+        print("[mdt-train] --wandb-project: metrics are printed as JSON lines, nothing is sent to wandb", file=sys.stderr)
     import torch.distributed as dist
     from .ddp import DataParallel
     from .optim import FusedAdam, PolynomialDecayLR
@@ -127,47 +154,112 @@ def main(argv=None):
     dp = DataParallel(model)
     dp.broadcast_parameters()
     crit_cls, _ = CRITERION_REGISTRY[args.criterion]
-    crit = crit_cls(task, positive_weight=args.positive_weight, negative_weight=args.negative_weight)
+    crit = crit_cls.build_criterion(args, task)      # constructor arguments by name from the flags, as FairSeq does
     betas = ast.literal_eval(args.adam_betas) if isinstance(args.adam_betas, str) else args.adam_betas
     opt = FusedAdam([p for p in model.parameters() if hasattr(p, "main_grad")], lr=args.lr, betas=betas, eps=args.adam_eps,
                     weight_decay=args.weight_decay)
     sched = PolynomialDecayLR(args.lr, args.end_learning_rate, args.warmup_updates, args.total_num_update, args.power)
+    from . import checkpoint as ckpt
+    start_update, epoch0 = 0, 1
+    if args.restore_file:
+        if not os.path.exists(args.restore_file):
+            raise SystemExit(f"[mdt-train] --restore-file {args.restore_file} does not exist")
+        info = ckpt.load_checkpoint(args.restore_file, model, optimizer=opt, reset_optimizer=args.reset_optimizer,
+                                    reset_lr_scheduler=args.reset_lr_scheduler, reset_meters=args.reset_meters,
+                                    reset_dataloader=args.reset_dataloader, allow_missing_prefixes=("node_encoder_stack.",))
+        start_update, epoch0 = info["num_updates"], info["epoch"]
+        if rank == 0:
+            print(json.dumps(dict(restored=args.restore_file, num_updates=start_update, optimizer=info["loaded_optimizer"],
+                                  missing=len(info["missing"]), unexpected=len(info["unexpected"]))), flush=True)
+        dp.broadcast_parameters()
 
-    if args.dataset_name == "synthetic" or task.dm is None:
+    if args.dataset_name == "synthetic":
         batches = synthetic_batches(args, task, rank)
+        n_batches = len(batches)
+
+        def batch_stream():
+            while True:
+                yield from batches
+    elif task.dm is None:
+        raise SystemExit(f"[mdt-train] dataset {args.dataset_name!r} is not registered: pass --user-data-dir <package whose "
+                         "modules call register_dataset> (mDT/src/tasks/task.py:123-137) or --dataset-name synthetic")
     else:
-        raise SystemExit("registered datasets are iterated by FairSeq's data pipeline, which is outside this launcher")
-    max_update = args.max_update or (args.max_epoch * len(batches) // max(1, args.update_freq)) or 50
+        # a registered dataset (mDT/src/tasks/task.py:168-204): rank r takes every world-th batch of the epoch order;
+        # batches are packed, uploaded and indexed one step ahead by the prefetch thread
+        from .data.prefetch import Prefetcher
+        task.collate_device = "cuda"
+        ds = task.load_dataset("train")
+        n_batches = max(1, len(ds) // (args.batch_size * world))
+
+        def index_stream():
+            epoch = epoch0
+            while True:
+                if hasattr(ds, "set_epoch"):
+                    ds.set_epoch(epoch)
+                order = list(ds.ordered_indices())
+                for b in range(n_batches):
+                    lo = (b * world + rank) * args.batch_size
+                    yield [int(i) for i in order[lo:lo + args.batch_size]]
+                epoch += 1
+
+        ge = model.encoder.graph_encoder
+
+        def make(idx):
+            sample = ds.collater([ds[i] for i in idx])
+            return sample["net_input"]["batched_data"]["_packed"]
+
+        def warm(pb):
+            ix = ge._indices(pb)
+            if ge.prune_last_layer:
+                ge._prune_indices(pb, ix)
+
+        batch_stream = lambda: Prefetcher(index_stream(), make, depth=2, warm=warm)   # noqa: E731
+    stream = iter(batch_stream())
+    if args.dataset_name == "synthetic" and start_update and not args.reset_dataloader:
+        for _ in range(start_update * args.update_freq):        # resume the batch order where the checkpoint left it
+            next(stream)
+    max_update = args.max_update or (args.max_epoch * n_batches // max(1, args.update_freq)) or 50
     scal = torch.zeros(6, dtype=torch.float32, device="cuda")
     history = []
     it = 0
     t0 = time.time()
-    for upd in range(1, max_update + 1):
+    lr_for = sched.for_update        # FairSeq's timing: update k runs with the rate of num_updates = k - 1
+
+    def save(path, upd):
+        ckpt.save_checkpoint(path, model, args, optimizer=opt, num_updates=upd, criterion_name=crit_cls.__name__,
+                             lr_scheduler_state={"best": None}, epoch=epoch0 + (it // max(1, n_batches)),
+                             training_time=time.time() - t0)
+
+    for upd in range(start_update + 1, max_update + 1):
         dp.zero_grad()
         acc = torch.zeros(6, dtype=torch.float32, device="cuda")
         for micro in range(args.update_freq):
             dp.accumulate(micro == args.update_freq - 1)
-            pb = batches[it % len(batches)]
+            pb = next(stream)
             it += 1
             loss, sample_size, log = crit(model, {"nsamples": pb.B, "net_input": {"batched_data": pb.batched_data}})
             loss.backward()
+            counter_keys = [k for k in log if k not in ("loss", "sample_size", "nsentences", "ntokens")]   # 4 per criterion
             acc[0] += loss.detach().float()
             acc[1] += float(sample_size)
-            acc[2:6] += torch.stack([log["ncorrect"], log["num_positive_correct"], log["total_positive"],
-                                     log["num_pred_positive"]]).float()
+            acc[2:6] += torch.stack([log[k] for k in counter_keys]).float()
         scal.copy_(acc)
         dp.finish_backward(scal)                 # all-reduce (world > 1) and divide by the global sample size
-        opt.step(lr=sched(upd))
+        opt.step(lr=lr_for(upd))
         if upd % args.log_interval == 0 or upd == max_update:
             s = scal.tolist()                    # the only host sync, once per log interval
-            m = crit_cls.compute_metrics([dict(loss=s[0], sample_size=s[1], ncorrect=s[2], num_positive_correct=s[3],
-                                               total_positive=s[4], num_pred_positive=s[5])])
-            m.update(num_updates=upd, lr=sched(upd), wall=round(time.time() - t0, 2))
+            m = crit_cls.compute_metrics([dict(loss=s[0], sample_size=s[1], **dict(zip(counter_keys, s[2:6])))])
+            m.update(num_updates=upd, lr=lr_for(upd), wall=round(time.time() - t0, 2))
             history.append(m)
             if rank == 0:
                 print(json.dumps(m), flush=True)
-    if args.save_checkpoint and rank == 0:
-        torch.save({"model": model.state_dict(), "args": vars(args)}, args.save_checkpoint)
+        if rank == 0 and args.save_dir and not args.no_save and args.save_interval_updates > 0 and upd % args.save_interval_updates == 0:
+            for path in ckpt.checkpoint_paths(args.save_dir, epoch0, upd):
+                save(path, upd)
+    if rank == 0 and args.save_checkpoint:
+        save(args.save_checkpoint, max_update)
+    if rank == 0 and args.save_dir and not args.no_save:
+        save(os.path.join(args.save_dir, "checkpoint_last.pt"), max_update)
     if world > 1:
         dist.destroy_process_group()
     return history

@@ -551,6 +551,42 @@ def case_contrastive(mods, models, collator_mod, pre, updown):
     np.savez_compressed(os.path.join(OUT, "contrastive.npz"), **out)
 
 
+def case_state_dict_keys(mods, models):
+    """Names and shapes of every state-dict entry of the reference model at the SHIPPED launch
+    (mDT/experiments/hateful_discussions/sample_run.sh:3 = `run_train.sh 8 4 5 2 2 0`, flags run_train.sh:28-65) built as
+    NodePredictionTask.build_model builds it (tasks/node_prediction.py:34-55) — the checkpoint-compatibility contract.
+    Inner names of the installed transformers 5.x are mapped to the 4.x names real checkpoints of the reference carry."""
+    import json
+    hp = R.hparams(dim=768, enc_heads=12, graph_heads=12, enc_ffn=3072, graph_ffn=768, text_layers=12, vit_layers=12,
+                   num_fusion_layers=8, num_fusion_stack=2, num_graph_stack=2, num_bottleneck=4)
+    mods.MultiGraphormerGraphEncoder.build_vit_bert_encoders = make_builder(hp)
+    args = SimpleNamespace(
+        max_nodes=10000, num_atoms=512 * 9, num_in_degree=512, num_out_degree=512, num_edges=512 * 3, num_spatial=512,
+        num_edge_dis=128, edge_type="multi_hop", multi_hop_max_dist=5, num_bottleneck_tokens=4, num_fusion_layers=8,
+        num_fusion_stack=2, num_graph_stack=2, encoder_layers=4, encoder_embed_dim=768, encoder_ffn_embed_dim=768,
+        encoder_attention_heads=12, dropout=0.4, attention_dropout=0.3, act_dropout=0.3, encoder_normalize_before=True,
+        pre_layernorm=False, apply_graphormer_init=False, activation_fn="gelu", freeze_initial_encoders=True,
+        share_encoder_input_output_embed=False, num_classes=1, remove_head=False)
+    enc = models.GraphormerEncoder(args)
+    model = models.GraphormerModel(args, enc)
+    model.node_encoder_stack = nn.ModuleList([enc.graph_encoder.text_pooler, enc.graph_encoder.text_dropout, nn.Linear(768, 2)])
+    GE = "encoder.graph_encoder."
+
+    def canon(k):
+        return GE + canonical(k[len(GE):]) if k.startswith(GE) else canonical(k)
+
+    keys = {}
+    for k, v in model.state_dict().items():
+        keys[canon(k)] = list(v.shape)
+    trainable = sorted(canon(k) for k, p in model.named_parameters() if p.requires_grad)
+    n_params = sum(p.numel() for p in model.parameters())
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    with open(os.path.join(OUT, "state_dict_keys_launch.json"), "w") as f:
+        json.dump(dict(launch="sample_run.sh:3 (8 4 5 2 2 0), --freeze_initial_encoders", n_keys=len(keys), n_params=n_params,
+                       n_trainable_params=n_train, keys=keys, trainable=trainable), f, indent=0, sort_keys=True)
+    print("state dict keys", len(keys), "params", n_params, "trainable", n_train)
+
+
 def case_fusion_layer(mods):
     from transformers import BertConfig, ViTConfig
     from transformers.models.bert.modeling_bert import BertLayer
@@ -607,6 +643,9 @@ def main():
     metrics = install_fairseq_standins()
     mods, models, collator_mod, pre, loss_mod = mount_reference()
     updown = load_updown_functions()
+    if only and only[0] == "keys":
+        case_state_dict_keys(mods, models)
+        return
     if only and only[0] == "contrastive":
         case_contrastive(mods, models, collator_mod, pre, updown)
         return
@@ -623,6 +662,7 @@ def main():
     print("full model done")
     case_contrastive(mods, models, collator_mod, pre, updown)
     print("contrastive done")
+    case_state_dict_keys(mods, models)
 
 
 if __name__ == "__main__":

@@ -483,3 +483,54 @@ def test_large_shaped_encoder_block_bf16(kind, S, nseq):
     rg = W[pre + "intermediate.dense.weight"].grad
     cos = float((rg * p.grad.float().cpu()).sum() / (rg.norm() * p.grad.float().norm().cpu()))
     assert cos > 0.99, cos
+
+
+def test_frozen_initial_encoders_stop_the_gradient_chain(monkeypatch):
+    """--freeze_initial_encoders (run_train.sh:61): the reference's autograd never enters the frozen embeddings /
+    pre-fusion layers.  Here too: no adjoint of the frozen prefix runs (counted by its GEMM launches), frozen parameters
+    get no gradient, and every trainable parameter gets exactly the gradient of the unfrozen model."""
+    from multimodaldiscussiontransformer_amd import engine
+    from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
+    from multimodaldiscussiontransformer_amd.data.packer import pack_batch
+    from multimodaldiscussiontransformer_amd.models import GraphormerModel
+    hp = cases.tiny_hparams("A")
+    trees = cases.tiny_trees("A", hp)
+    counts = {}
+    raw = engine.ops.gemm
+    phase = {"name": None}
+
+    def counting(*a, **kw):
+        if phase["name"]:
+            counts[phase["name"]] = counts.get(phase["name"], 0) + 1
+        return raw(*a, **kw)
+
+    monkeypatch.setattr(engine.ops, "gemm", counting)
+    res = {}
+    for frozen in (False, True):
+        model = GraphormerModel.build_model(model_args(hp, freeze_initial_encoders=frozen), task=None)
+        fill_hash_weights(model)
+        model = model.cuda().eval()
+        pb = pack_batch(trees, 5)
+        crit = GraphPredictionNodeCrossEntropy(None, positive_weight=1.5, negative_weight=1.0)
+        tag = "frozen" if frozen else "live"
+        phase["name"] = tag + "/fwd"
+        loss, _, _ = crit(model, {"nsamples": len(trees), "net_input": {"batched_data": pb.batched_data}})
+        phase["name"] = tag + "/bwd"
+        loss.backward()
+        phase["name"] = None
+        torch.cuda.synchronize()
+        res[frozen] = (float(loss.detach()), {n: (None if p.grad is None else p.grad.cpu()) for n, p in model.named_parameters()},
+                       {n: p.requires_grad for n, p in model.named_parameters()})
+    (l0, g0, _), (l1, g1, rq) = res[False], res[True]
+    assert l0 == l1 and counts["live/fwd"] == counts["frozen/fwd"]
+    n_frozen = 0
+    for n, g in g1.items():
+        if not rq[n]:
+            n_frozen += 1
+            assert g is None, n
+        elif g0[n] is not None:
+            torch.testing.assert_close(g, g0[n], atol=2e-5 * max(1.0, float(g0[n].abs().max())), rtol=1e-4, msg=n)
+    assert n_frozen > 30
+    # hp "A": 2 + 2 pre-fusion blocks (5 backward GEMMs each with weight gradients skipped: 4 dgrads + ... ) and the two
+    # embedding stages vanish from backward; what is left is the fusion / graph / head part
+    assert counts["frozen/bwd"] < 0.7 * counts["live/bwd"], counts

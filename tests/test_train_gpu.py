@@ -75,7 +75,7 @@ def test_launcher_trains_and_loss_decreases(tmp_path):
             "--synthetic-nodes", "8", "--synthetic-seq-len", "16", "--synthetic-batches", "4",
             "--bert-config", '{"dim": 128, "layers": 2, "heads": 2, "intermediate": 256, "vocab": 512, "max_pos": 64}',
             "--vit-config", '{"dim": 128, "layers": 2, "heads": 2, "intermediate": 256, "image_size": 32, "patch": 16}',
-            "--save-dir", "ignored", "--wandb-project", "ignored", "--save-checkpoint", str(ck), "--seed", "3"]
+            "--save-dir", str(tmp_path / "ckdir"), "--wandb-project", "ignored", "--save-checkpoint", str(ck), "--seed", "3"]
     hist = train.main(argv)
     assert len(hist) == 6
     first, last = hist[0]["loss"], hist[-1]["loss"]
@@ -84,6 +84,42 @@ def test_launcher_trains_and_loss_decreases(tmp_path):
     sd = torch.load(ck)["model"]
     assert "encoder.graph_encoder.layers.0.layers.0.self_attn.q_proj.weight" in sd
     assert "encoder.graph_encoder.fusion_layers.0.fusion_layers.0.bert_encoder.attention.self.query.weight" in sd
+
+
+def test_restore_file_resumes_training(tmp_path):
+    """--save-dir / --restore-file (run_train.sh:57-58): 8 updates in one run against 4 updates, a FairSeq-layout
+    checkpoint, and 4 more updates from it (optimizer moments, update count, LR schedule and batch order restored);
+    and --reset-optimizer, which keeps the weights but restarts the schedule."""
+    from multimodaldiscussiontransformer_amd import train
+
+    def argv(extra):
+        return ["--task", "node_prediction", "--arch", "multi_graphormer_base", "--criterion", "node_cross_entropy",
+                "--dataset-name", "synthetic", "--batch-size", "8", "--update-freq", "2", "--lr", "5e-4", "--end-learning-rate", "1e-5",
+                "--warmup-updates", "3", "--total-num-update", "8", "--encoder-embed-dim", "128", "--encoder-ffn-embed-dim", "128",
+                "--encoder-attention-heads", "2", "--num_fusion_layers", "0", "--num_bottleneck_tokens", "2",
+                "--attention-dropout", "0", "--act-dropout", "0", "--dropout", "0", "--spatial-pos-max", "5", "--log-interval", "1",
+                "--synthetic-nodes", "6", "--synthetic-seq-len", "12", "--synthetic-batches", "5", "--seed", "5",
+                "--bert-config", '{"dim": 128, "layers": 2, "heads": 2, "intermediate": 128, "vocab": 512, "max_pos": 64}',
+                "--vit-config", '{"dim": 128, "layers": 2, "heads": 2, "intermediate": 128, "image_size": 32, "patch": 16}'] + extra
+
+    full = train.main(argv(["--max-update", "8", "--no-save"]))
+    d = tmp_path / "ck"
+    first = train.main(argv(["--max-update", "4", "--save-dir", str(d)]))
+    ck = d / "checkpoint_last.pt"
+    st = torch.load(ck, weights_only=False)
+    assert st["optimizer_history"][-1]["num_updates"] == 4 and "last_optimizer_state" in st
+    second = train.main(argv(["--max-update", "8", "--restore-file", str(ck), "--no-save"]))
+    assert [h["num_updates"] for h in second] == [5, 6, 7, 8]
+    for a, b in zip(full[:4], first):
+        assert abs(a["loss"] - b["loss"]) <= 1e-4 * max(1.0, abs(a["loss"]))
+    for a, b in zip(full[4:], second):
+        assert a["num_updates"] == b["num_updates"] and abs(a["lr"] - b["lr"]) < 1e-12
+        assert abs(a["loss"] - b["loss"]) <= 2e-3 * max(1.0, abs(a["loss"])), (a, b)
+    fresh = train.main(argv(["--max-update", "2", "--restore-file", str(ck), "--reset-optimizer", "--no-save"]))
+    assert [h["num_updates"] for h in fresh] == [1, 2] and abs(fresh[0]["lr"] - 5e-4 / 3) < 1e-12
+    assert fresh[0]["loss"] < full[0]["loss"]                     # starts from trained weights, not from scratch
+    with pytest.raises(SystemExit):
+        train.main(argv(["--max-update", "1", "--curriculum", "3"]))      # unknown FairSeq flag: refuse, do not ignore
 
 
 def test_rccl_bucketed_exchange_world1_equals_plain_backward(monkeypatch):
