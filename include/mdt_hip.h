@@ -275,6 +275,12 @@ int mdt_adam_step_multi(void* stream, int dtype, int n_tensors, const mdt_adam_t
 int mdt_pack_structure(int B, const int64_t* n_nodes, const int64_t* const* parents, int nmax,
                        int spatial_pos_max, float* attn_bias /*[B,nmax+1,nmax+1]*/,
                        int32_t* spatial_pos /*[B,nmax,nmax]*/, int64_t* in_degree /*[B,nmax]*/);
+/* Same, with the (hops up, hops down) pairs of a tree given explicitly: updown[b] = i64[n_b, n_b, 2] or NULL (derive
+ * them from parents[b]).  The reference stores this matrix per graph (``distance_matrix``,
+ * experiments/hateful_discussions/datasets/hateful_discussions.py:148-165) and feeds it to preprocess_item; for a
+ * well-formed tree it is a function of the parent array, for discussions with repeated comment ids it is not. */
+int mdt_pack_structure_ud(int B, const int64_t* n_nodes, const int64_t* const* parents, const int64_t* const* updown,
+                          int nmax, int spatial_pos_max, float* attn_bias, int32_t* spatial_pos, int64_t* in_degree);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,7 @@ _SIGS = {
     "mdt_transpose2d": ([_vp, _i, _i, _i64, _i64, _vp, _i64, _vp, _i64], _i),
     "mdt_adam_step": ([_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _vp], _i),
     "mdt_pack_structure": ([_i, _vp, _vp, _i, _i, _vp, _vp, _vp], _i),
+    "mdt_pack_structure_ud": ([_i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp], _i),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -62,8 +62,9 @@ const SpatialTable kTable;
 
 }  // namespace
 
-extern "C" int mdt_pack_structure(int B, const int64_t* n_nodes, const int64_t* const* parents, int nmax,
-                                  int spatial_pos_max, float* attn_bias, int32_t* spatial_pos, int64_t* in_degree) {
+extern "C" int mdt_pack_structure_ud(int B, const int64_t* n_nodes, const int64_t* const* parents,
+                                     const int64_t* const* updown, int nmax, int spatial_pos_max, float* attn_bias,
+                                     int32_t* spatial_pos, int64_t* in_degree) {
   MDT_CHECK_ARG(B >= 0 && nmax >= 1 && n_nodes && parents && attn_bias && spatial_pos && in_degree,
                 "pack_structure: bad arguments");
   const int T = nmax + 1;
@@ -93,11 +94,18 @@ extern "C" int mdt_pack_structure(int B, const int64_t* n_nodes, const int64_t* 
     }
     for (int i = 0; i < n; ++i) {
       for (int j = 0; j < n; ++j) {
-        int a = i, c = j;  // walk both to their lowest common ancestor
         int up = 0, down = 0;
-        while (a != c) {
-          if (depth[a] >= depth[c]) { a = (int)par[a]; ++up; }
-          else { c = (int)par[c]; ++down; }
+        if (updown && updown[b]) {   // the dataset's own distance_matrix (hateful_discussions.py:148-165), taken as given
+          const int64_t* e = updown[b] + ((int64_t)i * n + j) * 2;
+          MDT_CHECK_ARG(e[0] >= 0 && e[1] >= 0 && e[0] < (1 << 20) && e[1] < (1 << 20), "pack_structure: tree %d: negative hop count", b);
+          up = (int)e[0];
+          down = (int)e[1];
+        } else {
+          int a = i, c = j;  // walk both to their lowest common ancestor
+          while (a != c) {
+            if (depth[a] >= depth[c]) { a = (int)par[a]; ++up; }
+            else { c = (int)par[c]; ++down; }
+          }
         }
         const int bucket = (up <= 5 && down <= 5) ? kTable.t[up][down] : kTable.t[5][5];
         sp[(int64_t)i * nmax + j] = bucket + 1;
@@ -106,4 +114,9 @@ extern "C" int mdt_pack_structure(int B, const int64_t* n_nodes, const int64_t* 
     }
   }
   return MDT_OK;
+}
+
+extern "C" int mdt_pack_structure(int B, const int64_t* n_nodes, const int64_t* const* parents, int nmax,
+                                  int spatial_pos_max, float* attn_bias, int32_t* spatial_pos, int64_t* in_degree) {
+  return mdt_pack_structure_ud(B, n_nodes, parents, nullptr, nmax, spatial_pos_max, attn_bias, spatial_pos, in_degree);
 }

@@ -21,8 +21,10 @@ import torch
 from .. import _lib as L
 
 
-def pack_structure(parents: List[np.ndarray], spatial_pos_max: int, nmax: Optional[int] = None):
-    """→ (attn_bias f32[B,T,T], spatial_pos i32[B,N,N], in_degree i64[B,N]) as numpy arrays."""
+def pack_structure(parents: List[np.ndarray], spatial_pos_max: int, nmax: Optional[int] = None, updown=None):
+    """→ (attn_bias f32[B,T,T], spatial_pos i32[B,N,N], in_degree i64[B,N]) as numpy arrays.  ``updown``: optional list
+    with, per tree, None or an explicit i64[n, n, 2] (hops up, hops down) matrix that replaces the one derived from the
+    parent array (include/mdt_hip.h, mdt_pack_structure_ud)."""
     B = len(parents)
     parents = [np.ascontiguousarray(p, dtype=np.int64) for p in parents]
     n_nodes = np.asarray([len(p) for p in parents], dtype=np.int64)
@@ -32,8 +34,16 @@ def pack_structure(parents: List[np.ndarray], spatial_pos_max: int, nmax: Option
     spatial_pos = np.empty((B, nmax, nmax), dtype=np.int32)
     in_degree = np.empty((B, nmax), dtype=np.int64)
     ptrs = (C.c_void_p * B)(*[p.ctypes.data for p in parents])
-    L.check(L.lib.mdt_pack_structure(B, n_nodes.ctypes.data, C.cast(ptrs, C.c_void_p), nmax, int(spatial_pos_max),
-                                     attn_bias.ctypes.data, spatial_pos.ctypes.data, in_degree.ctypes.data),
+    ud_arg = None
+    if updown is not None and any(u is not None for u in updown):
+        uds = [None if u is None else np.ascontiguousarray(u, dtype=np.int64) for u in updown]
+        for u, p in zip(uds, parents):
+            if u is not None and u.shape != (len(p), len(p), 2):
+                raise ValueError(f"updown matrix of shape {u.shape} for a tree of {len(p)} comments")
+        ud_ptrs = (C.c_void_p * B)(*[None if u is None else u.ctypes.data for u in uds])
+        ud_arg = C.cast(ud_ptrs, C.c_void_p)
+    L.check(L.lib.mdt_pack_structure_ud(B, n_nodes.ctypes.data, C.cast(ptrs, C.c_void_p), ud_arg, nmax, int(spatial_pos_max),
+                                        attn_bias.ctypes.data, spatial_pos.ctypes.data, in_degree.ctypes.data),
             "mdt_pack_structure")
     return attn_bias, spatial_pos, in_degree
 
@@ -113,7 +123,8 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
     N = max(n_nodes)
     Lq = trees[0]["input_ids"].shape[1]
     M = int(sum(n_nodes))
-    attn_bias, spatial_pos, in_degree = pack_structure([t["parent"] for t in trees], spatial_pos_max, N)
+    attn_bias, spatial_pos, in_degree = pack_structure([t["parent"] for t in trees], spatial_pos_max, N,
+                                                       updown=[t.get("updown") for t in trees])
     pin = torch.cuda.is_available() and str(device).startswith("cuda")
 
     def host(shape, dtype):

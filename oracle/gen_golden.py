@@ -587,6 +587,48 @@ def case_state_dict_keys(mods, models):
     print("state dict keys", len(keys), "params", n_params, "trainable", n_train)
 
 
+def case_discussions():
+    """Dataset-builder semantics of mDT/experiments/hateful_discussions/datasets/hateful_discussions.py on a synthetic
+    JSON-lines sample (tests/golden/discussions/sample.jsonl): the module needs torch_geometric, so the plain-Python
+    pieces are compiled from its text — the methods get_relative_depth / spread_downwards / collapse_tree and, out of
+    ``process``, the two URL regexes with the nested clean_urls / extract_text — and run exactly as ``process`` runs them
+    (:103-107).  Stored: node order, text handed to the tokenizer, labels and the (up, down) matrix of every discussion."""
+    import json
+    path = os.path.join(REF, "mDT/experiments/hateful_discussions/datasets/hateful_discussions.py")
+    tree = ast.parse(open(path).read())
+    methods, nested = [], []
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in ("get_relative_depth", "spread_downwards", "collapse_tree"):
+            methods.append(node)
+        if isinstance(node, ast.FunctionDef) and node.name == "process":
+            for sub in node.body:
+                if isinstance(sub, ast.Assign) and getattr(sub.targets[0], "id", "") in ("markdown_regex", "all_url_regex"):
+                    nested.append(sub)
+                if isinstance(sub, ast.FunctionDef) and sub.name in ("clean_urls", "extract_text"):
+                    nested.append(sub)
+    ns = {"copy": __import__("copy"), "re": __import__("re"), "print": lambda *a, **k: None}
+    exec(compile(ast.Module(body=methods + nested, type_ignores=[]), path, "exec"), ns)
+    H = type("Holder", (), {k: ns[k] for k in ("get_relative_depth", "spread_downwards", "collapse_tree")})()
+    src = os.path.join(OUT, "discussions", "sample.jsonl")
+    out = []
+    for line in open(src):
+        raw = json.loads(line)
+        H.get_relative_depth(raw)
+        H.spread_downwards(raw)
+        data = {}
+        H.collapse_tree(raw, data, [])
+        order = list(data.keys())
+        out.append(dict(
+            order=order,
+            texts=[ns["extract_text"](data[k]) for k in order],
+            labels=[data[k][3] for k in order],
+            images=[data[k][1] for k in order],
+            updown=[[data[a][2][b] for b in order] for a in order]))
+    with open(os.path.join(OUT, "discussions", "expected.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("discussions", [len(o["order"]) for o in out])
+
+
 def case_fusion_layer(mods):
     from transformers import BertConfig, ViTConfig
     from transformers.models.bert.modeling_bert import BertLayer
@@ -643,6 +685,9 @@ def main():
     metrics = install_fairseq_standins()
     mods, models, collator_mod, pre, loss_mod = mount_reference()
     updown = load_updown_functions()
+    if only and only[0] == "discussions":
+        case_discussions()
+        return
     if only and only[0] == "keys":
         case_state_dict_keys(mods, models)
         return
@@ -663,6 +708,7 @@ def main():
     case_contrastive(mods, models, collator_mod, pre, updown)
     print("contrastive done")
     case_state_dict_keys(mods, models)
+    case_discussions()
 
 
 if __name__ == "__main__":
