@@ -4,25 +4,32 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over one batch of synthetic discussion trees that is
-already resident in HBM: encoder (BERT / ViT blocks, bottleneck fusion, Graphormer attention)
-→ head → weighted CE → backward → (N > 1) RCCL gradient all-reduce overlapped with backward.
-Workload (BASELINE.json configs[1]): mDT-base — BERT-base + ViT-B/16 split 6 + 6, 6 executed
-graph layers, D 768, 12 heads, nb 4, L 100 — on 32 bushy 64-comment trees per GPU with 25 % image
-comments, bf16 activations / weights, fp32 softmax, LayerNorm statistics and gradient arena,
-dropout ON at the reference launch's rates (0.4 / 0.3 / 0.3; --dropout 0 ... turns it off).
-Weak scaling: every rank processes its own 32 trees, no data-path collective except the
-gradient all-reduce.
+A step = one pass of the hot path over one batch of synthetic discussion trees that the step has NOT
+seen before: native packer → pinned host buffers → asynchronous H2D → index vectors (all of it one batch ahead, in a
+prefetch thread on a copy stream, data/prefetch.py) → encoder (BERT / ViT blocks, bottleneck fusion, Graphormer
+attention) → head → weighted CE → backward → (N > 1) RCCL gradient all-reduce overlapped with backward.  The trees
+themselves (numpy arrays) are generated before the timed region — generating random data is not part of the path.
+Workloads:
+  --config base (default; BASELINE.json configs[1]): mDT-base — BERT-base + ViT-B/16 split 6 + 6, 6 executed graph
+      layers, D 768, 12 heads, nb 4, L 100 — 32 bushy 64-comment trees per GPU, 25 % image comments
+  --config large (configs[3] shapes): mDT-large — BERT-large + ViT-L/14 split 12 + 12, 12 executed graph layers, D 1024,
+      16 heads — 8 deep-thread 128-comment trees per GPU (banded -inf structural mask), 25 % image comments
+bf16 activations / weights, fp32 softmax, LayerNorm statistics and gradient arena, dropout ON at the reference
+launch's rates (0.4 / 0.3 / 0.3; --dropout 0 ... turns it off).  Weak scaling: every rank processes its own trees
+(assigned by token cost, ddp.balance_trees), no data-path collective except the gradient all-reduce.
 
 Rank 0 prints ONE JSON line (contract in the task description) carrying
-  roofline      the dominant kernel (bf16 MFMA tile GEMM): algorithmic FLOPs of its launches /
-                their summed duration, measured live with HIP events on the launch stream in a
-                pass of the same steps on ONE stream right after the timed region (the timed
-                region overlaps the text and image branches on two HIP streams, where an event
-                bracket also times the wait for compute units held by the other branch);
+  value / ms_per_step   all comments of the timed steps / wall time between the two barrier + synchronize brackets
+  ms_per_step_median    median over the timed steps of the per-step time (HIP events at the step boundaries)
+  packer_h2d_ms         copy-stream time per batch (pack + H2D + index build) — overlapped with the previous step
+  roofline      the dominant kernel (bf16 MFMA tile GEMM): algorithmic FLOPs of its launches / their summed duration,
+                measured live with HIP events on the launch stream in a pass of the same steps on ONE stream right
+                after the timed region (the timed region overlaps the text and image branches on two HIP streams,
+                where an event bracket also times the wait for compute units held by the other branch);
                 peak = 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md)
-  cpu_baseline  the oracle (CPU restatement of the reference math, fp32, torch CPU) timed on
-                this box's host cores on a bounded sample of the same workload (rank 0, N = 1).
+  cpu_baseline  the oracle (CPU restatement of the reference math, fp32, torch CPU) timed on this box's host cores on
+                a bounded sample of the same workload (2 trees of the workload's own size) and, for --config base, on
+                BASELINE.json configs[0] in full (rank 0, N = 1).
 """
 from __future__ import annotations
 
@@ -48,16 +55,29 @@ import multimodaldiscussiontransformer_amd  # noqa: E402,F401  (sets GPU_MAX_HW_
 BF16_DENSE_PEAK_TFLOPS = 2500.0
 
 
+CONFIGS = {
+    # BASELINE.json configs[1]
+    "base": dict(dim=768, heads=12, ffn=3072, layers=12, patch=16, image=224, trees=32, nodes=64, shape="bushy",
+                 name="mDT-base (BERT-base + ViT-B/16 split 6+6, 6 executed graph layers, D768 H12 nb4 L100)"),
+    # BASELINE.json configs[3]: BERT-large + ViT-L/14, 12 graph layers, 128-node deep threads
+    "large": dict(dim=1024, heads=16, ffn=4096, layers=24, patch=14, image=224, trees=8, nodes=128, shape="deep",
+                  name="mDT-large (BERT-large + ViT-L/14 split 12+12, 12 executed graph layers, D1024 H16 nb4 L100)"),
+}
+
+
 def base_args(a):
+    c = CONFIGS[a.config]
     return SimpleNamespace(
         num_atoms=512 * 9, num_in_degree=512, num_out_degree=512, num_edges=512 * 3, num_spatial=512, num_edge_dis=128,
         edge_type="multi_hop", multi_hop_max_dist=5, num_bottleneck_tokens=4, num_fusion_layers=a.num_fusion_layers,
-        num_fusion_stack=1, num_graph_stack=1, encoder_layers=4, encoder_embed_dim=768, encoder_ffn_embed_dim=768,
-        encoder_attention_heads=12, dropout=a.dropout, attention_dropout=a.attention_dropout, act_dropout=a.act_dropout,
+        num_fusion_stack=1, num_graph_stack=1, encoder_layers=4, encoder_embed_dim=c["dim"], encoder_ffn_embed_dim=c["dim"],
+        encoder_attention_heads=c["heads"], dropout=a.dropout, attention_dropout=a.attention_dropout, act_dropout=a.act_dropout,
         encoder_normalize_before=True,
         pre_layernorm=False, apply_graphormer_init=False, activation_fn="gelu",
         freeze_initial_encoders=a.freeze_initial_encoders, share_encoder_input_output_embed=False, max_nodes=10000,
-        num_classes=1)
+        num_classes=1,
+        bert_config=dict(dim=c["dim"], layers=c["layers"], heads=c["heads"], intermediate=c["ffn"]),
+        vit_config=dict(dim=c["dim"], layers=c["layers"], heads=c["heads"], intermediate=c["ffn"], image_size=c["image"], patch=c["patch"]))
 
 
 def flops_per_comment(L=100, nb=4, P=197, D=768, F=3072, Lb=6, Lf=6, G=6, N=64, Fg=768, rho=0.25, patch=16, lens=None,
@@ -155,34 +175,40 @@ class GemmTimer:
 
 
 def cpu_baseline(args):
-    """Oracle (CPU restatement) fwd+bwd on a bounded sample; comments/s on the host cores."""
+    """Oracle (CPU restatement of the reference math, fp32) fwd+bwd on the host cores: (1) a bounded sample of the
+    timed workload — 2 trees of its own shape (base: 2 x 64 comments, the §8d sample; large: cut to 24 comments per
+    tree so that the pass stays within ~20 s) — and (2) for --config base, BASELINE.json configs[0] ("Tiny mDT": 2-layer
+    graph, 128-d, BERT-mini 2 + 2 text only, 8 trees x 16 comments) in full."""
     from multimodaldiscussiontransformer_amd import synthetic
     from oracle import mdt_ref_cpu as R
     from oracle import structure as S
     ncores = host_cores()
     torch.set_num_threads(ncores)
-    hp = R.hparams(dim=768, enc_heads=12, graph_heads=12, enc_ffn=3072, graph_ffn=768, text_layers=12, vit_layers=12,
-                   num_fusion_layers=args.num_fusion_layers, num_fusion_stack=1, num_graph_stack=1, num_bottleneck=4,
-                   pos_weight=1.5, neg_weight=1.0)
-    n_trees, n_nodes = 2, 16
-    trees = synthetic.make_trees(n_trees, n_nodes, seed=4321, seq_len=100, image_frac=0.25, image_size=224)
-    batch = R.to_torch_batch(S.collate(trees, 5))
-    g = torch.Generator().manual_seed(0)
-    W = {n: (torch.randn(s, generator=g) * 0.02).requires_grad_(True) for n, s in R.param_shapes(hp).items()}
-    def one_pass():
-        for w in W.values():
-            w.grad = None
-        logits, _ = R.model_forward(W, hp, batch)
-        loss, _ = R.node_cross_entropy(logits, batch["y"], batch["y_mask"], hp)
-        loss.backward()
+    c = CONFIGS[args.config]
 
-    one_pass()                                   # untimed: thread pool, allocator and oneDNN primitives warm
-    passes, t0 = 0, time.time()
-    while passes < 12 and (passes == 0 or time.time() - t0 < 12.0):   # ~12 s of CPU work, at most 12 passes
-        one_pass()
-        passes += 1
-    dt = time.time() - t0
-    m = n_trees * n_nodes * passes
+    def timed(hp, trees, budget_s, max_passes):
+        batch = R.to_torch_batch(S.collate(trees, 5))
+        g = torch.Generator().manual_seed(0)
+        W = {n: (torch.randn(s, generator=g) * 0.02).requires_grad_(True) for n, s in R.param_shapes(hp).items()}
+
+        def one_pass(b):
+            for w in W.values():
+                w.grad = None
+            logits, _ = R.model_forward(W, hp, b)
+            loss, _ = R.node_cross_entropy(logits, b["y"], b["y_mask"], hp)
+            loss.backward()
+
+        # untimed: thread pool, allocator and oneDNN primitives warm on a 2 x 3-comment batch of the same model
+        small = synthetic.make_trees(2, 3, seed=1, seq_len=trees[0]["input_ids"].shape[1], image_frac=0.34 if trees[0]["images"] is not None else 0.0,
+                                     image_size=hp.image_size)
+        one_pass(R.to_torch_batch(S.collate(small, 5)))
+        passes, t0 = 0, time.time()
+        while passes < max_passes and (passes == 0 or time.time() - t0 < budget_s):
+            one_pass(batch)
+            passes += 1
+        dt = time.time() - t0
+        return sum(len(t["parent"]) for t in trees) * passes / dt, passes, dt
+
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -191,9 +217,25 @@ def cpu_baseline(args):
                 break
     except OSError:
         pass
-    return dict(value=m / dt, unit="comments/s", cores=ncores, kind="port",
-                sample=f"oracle (torch CPU fp32 restatement) fwd+bwd, {n_trees} trees x {n_nodes} comments, "
-                       f"25% image comments, mDT-base, {passes} timed passes after 1 warm-up, {dt:.1f} s on {model}")
+    hp = R.hparams(dim=c["dim"], enc_heads=c["heads"], graph_heads=c["heads"], enc_ffn=c["ffn"], graph_ffn=c["dim"],
+                   text_layers=c["layers"], vit_layers=c["layers"], num_fusion_layers=args.num_fusion_layers, num_fusion_stack=1,
+                   num_graph_stack=1, num_bottleneck=4, image_size=c["image"], patch=c["patch"], pos_weight=1.5, neg_weight=1.0)
+    n_nodes = c["nodes"] if args.config == "base" else 24
+    trees = synthetic.make_trees(2, n_nodes, seed=4321, seq_len=100, image_frac=args.image_frac, image_size=c["image"], shape=c["shape"])
+    v, passes, dt = timed(hp, trees, 10.0, 4)
+    out = dict(value=v, unit="comments/s", cores=ncores, kind="port",
+               sample=f"oracle (torch CPU fp32 restatement) fwd+bwd, 2 {c['shape']} trees x {n_nodes} comments, "
+                      f"{int(args.image_frac * 100)}% image comments, {c['name'].split(' (')[0]}, {passes} timed pass(es) after a small warm-up, "
+                      f"{dt:.1f} s on {model}")
+    if args.config == "base":
+        hp1 = R.hparams(dim=128, enc_heads=2, graph_heads=8, enc_ffn=512, graph_ffn=128, text_layers=4, vit_layers=4,
+                        num_fusion_layers=1, num_fusion_stack=1, num_graph_stack=1, num_bottleneck=4, pos_weight=1.5, neg_weight=1.0)
+        t1 = synthetic.make_trees(8, 16, seed=4322, seq_len=100, image_frac=0.0)
+        v1, p1, d1 = timed(hp1, t1, 4.0, 40)
+        out["config0_tiny"] = dict(value=v1, unit="comments/s", cores=ncores,
+                                   sample=f"BASELINE.json configs[0] in full: Tiny mDT (128-d, BERT-mini 2+2, 2 graph layers, text only), "
+                                          f"8 trees x 16 comments, {p1} timed passes, {d1:.1f} s")
+    return out
 
 
 def selfcheck():
@@ -345,10 +387,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--trees", type=int, default=32, help="trees per GPU")
-    ap.add_argument("--nodes", type=int, default=64)
+    ap.add_argument("--config", default="base", choices=sorted(CONFIGS))
+    ap.add_argument("--trees", type=int, default=0, help="trees per GPU (default: the config's)")
+    ap.add_argument("--nodes", type=int, default=0)
     ap.add_argument("--image-frac", type=float, default=0.25)
-    ap.add_argument("--num_fusion_layers", type=int, default=5)
+    ap.add_argument("--num_fusion_layers", type=int, default=-1, help="default: half of the encoder depth - 1 (base 5, large 11)")
     ap.add_argument("--freeze_initial_encoders", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.4, help="reference launch: run_train.sh:37")
     ap.add_argument("--attention-dropout", type=float, default=0.3)
@@ -357,9 +400,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
     ap.add_argument("--no-selfcheck", action="store_true", help="skip the numerics guard that runs before the warm-up")
+    ap.add_argument("--resident-batches", action="store_true",
+                    help="round-1 behaviour: alternate two pre-packed HBM-resident batches instead of streaming fresh ones")
     ap.add_argument("--with-optimizer", action="store_true",
                     help="also run the fused Adam update inside every timed step (the headline metric is fwd+bwd only)")
     args = ap.parse_args()
+    for var in ("MDT_GEMM_DIAG", "MDT_GEMM_STAMP"):
+        if os.environ.get(var):
+            raise SystemExit(f"bench.py refuses to run with {var} set: it changes what the GEMM kernels do (diagnostics only)")
+    cfg = CONFIGS[args.config]
+    args.trees = args.trees or cfg["trees"]
+    args.nodes = args.nodes or cfg["nodes"]
+    if args.num_fusion_layers < 0:
+        args.num_fusion_layers = cfg["layers"] // 2 - 1
 
     import torch.distributed as dist
     torch.set_num_threads(host_cores())
@@ -373,6 +426,7 @@ def main():
     if os.environ.get("MDT_SINGLE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    backend = None
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also at --nproc-per-node 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("MDT_DIST_BACKEND", "nccl")
@@ -384,7 +438,8 @@ def main():
     from multimodaldiscussiontransformer_amd import synthetic
     from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
     from multimodaldiscussiontransformer_amd.data.packer import pack_batch
-    from multimodaldiscussiontransformer_amd.ddp import DataParallel
+    from multimodaldiscussiontransformer_amd.data.prefetch import Prefetcher
+    from multimodaldiscussiontransformer_amd.ddp import DataParallel, balance_trees
     from multimodaldiscussiontransformer_amd.models import GraphormerModel
 
     if args.dtype == "bf16" and not args.no_selfcheck:
@@ -403,27 +458,53 @@ def main():
     if args.with_optimizer:
         from multimodaldiscussiontransformer_amd.optim import FusedAdam
         opt = FusedAdam([p for p in model.parameters() if hasattr(p, "main_grad")], lr=3e-5, weight_decay=0.01)
+    ge_ = model.encoder.graph_encoder
 
-    nbatch = 2
-    batches = []
-    for i in range(nbatch):
-        trees = synthetic.make_trees(args.trees, args.nodes, seed=1234 + rank * 1000 + i, seq_len=100,
-                                     image_frac=args.image_frac, image_size=224)
-        batches.append(pack_batch(trees, spatial_pos_max=5))
+    # ---- synthetic trees (host arrays), generated BEFORE anything is timed.  Every step gets its own batch; image
+    # pixels are windows (views) of one shared pool of random images at per-tree random offsets, so that the host holds
+    # one pool instead of 308 MB per batch.  With N > 1 the global batch of a step is dealt to the ranks by token cost.
+    n_roof = max(1, min(args.steps, 4))
+    n_stream = args.warmup + args.steps + 1
+    per_tree_img = int(round(args.image_frac * args.nodes))
+    rng_pool = np.random.Generator(np.random.PCG64(99 + rank))
+    pool = rng_pool.standard_normal((max(per_tree_img * 6, 1) + 64, 3, cfg["image"], cfg["image"]), dtype=np.float32) if per_tree_img else None
+
+    def trees_of_step(i):
+        kw = dict(seq_len=100, image_frac=args.image_frac, image_size=cfg["image"], shape=cfg["shape"], image_pool=pool)
+        if world == 1:
+            return synthetic.make_trees(args.trees, args.nodes, seed=1234 + i, **kw)
+        # the same global batch on every rank (seeded), each rank keeps its share: greedy token-cost balancing (§8e)
+        glob = synthetic.make_trees(args.trees * world, args.nodes, seed=1234 + i, variable=True, **kw)
+        nb_, Lq, P_ = 4, 100, (cfg["image"] // cfg["patch"]) ** 2 + 1
+        share = balance_trees([len(t["parent"]) for t in glob], [int(t["image_index"].sum()) for t in glob], world,
+                              text_tokens=Lq + nb_, image_tokens=P_ + nb_)
+        return [glob[j] for j in share[rank]]
+
+    t_gen = time.perf_counter()
+    n_distinct = 2 if args.resident_batches else n_stream
+    host_trees = [trees_of_step(i) for i in range(n_distinct)]
+    t_gen = time.perf_counter() - t_gen
+
+    def warm_indices(pb):
+        ix = ge_._indices(pb)
+        if ge_.prune_last_layer:
+            ge_._prune_indices(pb, ix)
+
     torch.cuda.synchronize()
+    check_batch = pack_batch(host_trees[0], spatial_pos_max=5)
     model_check = None
     if args.dtype == "bf16" and not args.no_selfcheck:
-        model_check = selfcheck_model(model, batches[0],
-                                      lambda: GraphormerModel.build_model(base_args(args), task=None).cuda().float(), crit)
-    comments_per_step = batches[0].M
+        model_check = selfcheck_model(model, check_batch, lambda: GraphormerModel.build_model(base_args(args), task=None).cuda().float(), crit)
+    tok_lens = check_batch.text_mask.sum(1).tolist()
     scal = torch.zeros(6, dtype=torch.float32, device="cuda")
-
     host_marks = []
+    resident = [check_batch, pack_batch(host_trees[1 % n_distinct], spatial_pos_max=5)] if args.resident_batches else None
+    if not args.resident_batches:
+        del check_batch
 
-    def step(i, marks=None):
+    def step(pb, marks=None):
         mark = (lambda name: marks.append((name, time.perf_counter()))) if marks is not None else (lambda name: None)
         mark("start")
-        pb = batches[i % nbatch]
         dp.zero_grad()
         sample = {"nsamples": pb.B, "net_input": {"batched_data": pb.batched_data}}
         mark("zero_grad")
@@ -447,54 +528,75 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.resident_batches:
+        batches = (resident[i % 2] for i in range(10 ** 9))
+        pf = None
+    else:
+        pf = Prefetcher(iter(host_trees), lambda ts: pack_batch(ts, spatial_pos_max=5), depth=2, warm=warm_indices)
+        batches = pf
+    comments = []
     for i in range(args.warmup):
-        step(i)
+        step(next(batches))
     fence()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    ev[0].record()
     for i in range(args.steps):
-        step(i)
+        pb = next(batches)
+        comments.append(pb.M)
+        step(pb)
+        ev[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
+    step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
+    ms_median = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     # host time to ENQUEUE one step (no sync inside a step), taken on an idle GPU: inside the back-to-back timed region
     # the HIP runtime holds the host back once its queues are full, so the loop's host time there just mirrors the GPU's
+    last = next(batches)
     t1 = time.perf_counter()
-    step(args.steps, host_marks)
+    step(last, host_marks)
     t_issue = time.perf_counter() - t1
     fence()
     host_phases = {b[0]: round((b[1] - a[1]) * 1e3, 2) for a, b in zip(host_marks, host_marks[1:])}
-    # roofline pass, after the timed region: the same steps on ONE HIP stream with a HIP-event bracket around every GEMM
-    # launch.  In the timed region the text and image branches run on two streams and their kernels overlap, so a
-    # bracket there times "this kernel plus its wait for compute units held by the other branch", not the kernel.
+    packer_ms = round(pf.copy_ms_per_batch(), 2) if pf is not None else None
+    packer_host_ms = round(pf.stats["pack_host_s"] / max(1, pf.stats["batches"]) * 1e3, 2) if pf is not None else None
+    # roofline pass, after the timed region: the same kind of steps on ONE HIP stream with a HIP-event bracket around
+    # every GEMM launch.  In the timed region the text and image branches run on two streams and their kernels overlap,
+    # so a bracket there times "this kernel plus its wait for compute units held by the other branch", not the kernel.
     dt_single = None
-    ge_ = model.encoder.graph_encoder
     if not args.no_gemm_timer:
         two = ge_.two_streams
         ge_.two_streams = False
-        n_roof = max(1, min(args.steps, 4))
-        for i in range(nbatch):     # untimed: the one-stream layout takes its blocks from the main stream's pool for the first time
-            step(i)
+        roof = [last, pack_batch(host_trees[0], spatial_pos_max=5)]
+        for pb in roof:             # untimed: the one-stream layout takes its blocks from the main stream's pool for the first time
+            step(pb)
         timer.enabled = True
         fence()
         t1 = time.perf_counter()
         for i in range(n_roof):
-            step(i)
+            step(roof[i % 2])
         fence()
         dt_single = (time.perf_counter() - t1) / n_roof
         timer.enabled = False
         ge_.two_streams = two
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([dt, float(sum(comments))], dtype=torch.float64, device="cuda")
     if dist.is_initialized():
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    total_comments = comments_per_step * world * args.steps
+        both = [torch.zeros_like(tot) for _ in range(world)]
+        dist.all_gather(both, tot)
+        dt = max(float(b[0]) for b in both)
+        total_comments = sum(float(b[1]) for b in both)
+        per_rank_comments = [int(b[1]) for b in both]
+    else:
+        total_comments = float(sum(comments))
+        per_rank_comments = [int(total_comments)]
     value = total_comments / dt
 
     if rank == 0:
-        ragged = bool(model.encoder.graph_encoder.ragged_tokens)
-        tok_lens = batches[0].text_mask.sum(1).tolist()
-        fkw = dict(Lb=12 - (args.num_fusion_layers + 1), Lf=args.num_fusion_layers + 1, G=args.num_fusion_layers + 1,
-                   N=args.nodes, rho=args.image_frac)
-        pruned = bool(model.encoder.graph_encoder.prune_last_layer)
+        ragged = bool(ge_.ragged_tokens)
+        Lf = args.num_fusion_layers + 1
+        fkw = dict(Lb=cfg["layers"] - Lf, Lf=Lf, G=Lf, N=args.nodes, rho=args.image_frac, D=cfg["dim"], F=cfg["ffn"], Fg=cfg["dim"],
+                   P=(cfg["image"] // cfg["patch"]) ** 2 + 1, patch=cfg["patch"])
+        pruned = bool(ge_.prune_last_layer)
         fpc = flops_per_comment(lens=tok_lens if ragged else None, prune_last=pruned, **fkw)   # FLOPs this implementation executes
         fpc_padded = flops_per_comment(**fkw)                                  # FLOPs of the reference's padded layout
         gs = timer.summary()
@@ -507,7 +609,7 @@ def main():
             import re
             cand = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")),
                           key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])      # round, version: numeric order
-            if cand:
+            if cand and args.config == "base":
                 traffic = json.load(open(cand[-1]))["gemm_family_bytes_per_launch"]
                 traffic_src = "profiles/" + os.path.basename(cand[-1])
         except (OSError, KeyError, ValueError):
@@ -517,32 +619,39 @@ def main():
                             peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(gs["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4),
                             traffic=traffic, traffic_unit="bytes per launch (fabric-side FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)", traffic_source=traffic_src,
                             algorithmic_bytes_per_launch=round(gs["bytes"] / gs["launches"]) if gs.get("bytes") else None, launches=gs["launches"], avg_launch_us=round(gs["avg_us"], 1),
-                            share_of_step=round(gs["total_ms"] * 1e-3 / (dt_single * max(1, min(args.steps, 4))), 3),
-                            measured=f"HIP events around every launch in a separate pass of {max(1, min(args.steps, 4))} steps on one HIP stream right after the "
+                            share_of_step=round(gs["total_ms"] * 1e-3 / (dt_single * n_roof), 3),
+                            measured=f"HIP events around every launch in a separate pass of {n_roof} steps on one HIP stream right after the "
                                      f"timed region ({round(dt_single * 1e3, 2)} ms per step there; the timed region overlaps the two branches on two streams)")
+        n_com = total_comments / args.steps / world
         out = {
             "metric": "discussion-tree comments/sec fwd+bwd", "value": round(value, 1), "unit": "comments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "mDT-base (BERT-base + ViT-B/16 split 6+6, 6 executed graph layers, D768 H12 nb4 L100), "
-                                   f"{args.trees} bushy {args.nodes}-comment trees per GPU, {int(args.image_frac * 100)}% image comments, "
+            "config": {"workload": f"{cfg['name']}, {args.trees} {cfg['shape']} {args.nodes}-comment trees per GPU, "
+                                   f"{int(args.image_frac * 100)}% image comments, "
                                    f"random-init weights, dropout {args.dropout}/{args.attention_dropout}/{args.act_dropout} (run_train.sh:37), "
                                    f"token lengths U{{8..100}} zero-padded to 100 (SURVEY.md §8d; mean {sum(tok_lens) / len(tok_lens):.1f} valid tokens), "
                                    + ("text side ragged: padded token positions are not computed (identical logits / gradients), "
                                       if ragged else "text side padded to 100 tokens as in the reference, ")
                                    + ("last fusion layer computes only the rows read afterwards, " if pruned else "")
+                                   + ("every step packs, uploads and indexes a batch it has not seen (prefetch thread, copy stream), "
+                                      if pf is not None else "two pre-packed HBM-resident batches alternate, ")
                                    + ("fused Adam step included" if opt is not None else "no optimizer step (metric: fwd+bwd)"),
-                       "trees_per_gpu": args.trees, "comments_per_step_per_gpu": comments_per_step,
+                       "name": args.config, "trees_per_gpu": args.trees, "comments_per_step_per_gpu": round(n_com, 1),
                        "parallelism": f"dp{world}", "frozen_initial_encoders": bool(args.freeze_initial_encoders)},
+            "ms_per_step_median": round(ms_median, 2),
+            "packer_h2d_ms": packer_ms, "packer_host_ms": packer_host_ms, "tree_generation_s_untimed": round(t_gen, 2),
             "model_tflops": round(value * 3 * fpc / 1e12, 1),
             "model_frac_of_bf16_peak": round(value * 3 * fpc / 1e12 / (BF16_DENSE_PEAK_TFLOPS * world), 4),
             "padded_equivalent_tflops": round(value * 3 * fpc_padded / 1e12, 1),
             "text_layout": "ragged" if ragged else "padded",
-            "compute_streams": 2 if model.encoder.graph_encoder.two_streams else 1,     # image branch beside the text branch
+            "compute_streams": 2 if ge_.two_streams else 1,     # image branch beside the text branch
             "host_issue_ms_per_step": round(t_issue * 1e3, 2), "host_issue_phases_ms": host_phases,
             "roofline": roofline,
             "selfcheck": "skipped" if (args.no_selfcheck or args.dtype != "bf16") else dict(kernels="passed", **(model_check or {})),
         }
+        if world > 1:
+            out["distributed"] = dict(world=world, backend=backend, comments_per_rank=per_rank_comments, **dp.diagnostics())
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

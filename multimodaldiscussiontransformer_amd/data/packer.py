@@ -152,7 +152,7 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
         key_pad[b, n + 1:] = 1
         img_index.append(np.asarray(t["image_index"], dtype=bool))
         if t["images"] is not None and len(t["images"]):
-            images.append(torch.from_numpy(np.ascontiguousarray(t["images"], dtype=np.float32)))
+            images.append(t["images"])
         ys.append(np.asarray(t["y"], dtype=np.float32).reshape(-1))
         # node task: which comments carry a label; graph-level (contrastive) trees have one y per tree and no mask
         y_masks.append(np.asarray(t["y_mask"], dtype=bool) if "y_mask" in t else np.zeros(n, dtype=bool))
@@ -168,11 +168,20 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
         raise ValueError("y must hold exactly one entry per True in y_mask")
     img_comment = torch.from_numpy(np.nonzero(img_index)[0].astype(np.int32))
     label_rows = torch.from_numpy(np.nonzero(y_mask)[0].astype(np.int32))
-    images_t = torch.cat(images) if images else None
-    if images_t is not None and pin:
-        images_t = images_t.pin_memory()
-    if images_t is not None and images_t.shape[0] != img_comment.numel():
-        raise ValueError("number of image tensors differs from the number of image-bearing comments")
+    images_t = None
+    if images:
+        # one pinned buffer, every tree's pixels copied into it once (308 MB per C2 batch: a torch.cat followed by
+        # pin_memory() would move them twice and keep the packer thread behind the training step)
+        n_img = sum(int(im.shape[0]) for im in images)
+        if n_img != img_comment.numel():
+            raise ValueError("number of image tensors differs from the number of image-bearing comments")
+        images_t = torch.empty((n_img,) + tuple(images[0].shape[1:]), dtype=torch.float32, pin_memory=pin)
+        o = 0
+        for im in images:
+            k = int(im.shape[0])
+            src = im if torch.is_tensor(im) else torch.from_numpy(np.asarray(im))
+            images_t[o:o + k].copy_(src)           # converts a non-fp32 source on the way
+            o += k
 
     def to(t):
         return None if t is None else t.to(device, non_blocking=non_blocking)

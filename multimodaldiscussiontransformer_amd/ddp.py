@@ -23,13 +23,35 @@ import torch
 import torch.distributed as dist
 
 
+def balance_trees(n_nodes: List[int], n_images: List[int], world: int, text_tokens: int = 104, image_tokens: int = 201) -> List[List[int]]:
+    """Deal the trees of a global batch to ``world`` ranks by token cost: tree i costs
+    ``N_i * (L + nb) + I_i * (P + nb)`` encoder tokens (an image comment is ~3x a text comment).  Greedy longest-
+    processing-time assignment: trees in decreasing cost (ties by index) each go to the rank with the smallest load so far
+    (ties by rank) — deterministic, so every rank computes the same deal from the same seeded batch without any
+    communication.  Returns, per rank, the tree indices in their original order."""
+    cost = [int(n) * text_tokens + int(i) * image_tokens for n, i in zip(n_nodes, n_images)]
+    order = sorted(range(len(cost)), key=lambda k: (-cost[k], k))
+    load = [0] * world
+    share: List[List[int]] = [[] for _ in range(world)]
+    for k in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        share[r].append(k)
+        load[r] += cost[k]
+    return [sorted(sh) for sh in share]
+
+
 class GradientBucketer:
     """Backend-agnostic core (works on CPU tensors with gloo — that is how it is tested)."""
 
     def __init__(self, params: List[torch.nn.Parameter], flat: torch.Tensor, bucket_bytes: int = 64 << 20,
-                 process_group=None, comm_stream: Optional["torch.cuda.Stream"] = None):
+                 process_group=None, comm_stream: Optional["torch.cuda.Stream"] = None, wire_dtype: Optional[torch.dtype] = None):
         self.params = [p for p in params if p.requires_grad]
         self.flat = flat
+        # what travels over xGMI: the fp32 arena itself (default: the sum over ranks is then exactly what one process
+        # would have accumulated) or a bf16 copy of each bucket (half the bytes; FairSeq's --fp16 trainer all-reduces
+        # half-precision gradients too) that is summed by RCCL and added back into the fp32 arena
+        self.wire_dtype = wire_dtype if wire_dtype not in (None, torch.float32) else None
+        self.bucket_events = []
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.pg = process_group
         self.comm_stream = comm_stream
@@ -98,6 +120,7 @@ class GradientBucketer:
 
     # -- per-step state -------------------------------------------------------------------
     def reset(self):
+        self._pending_wire = []
         self.ready = [False] * len(self.slots)
         self.cursor = 0            # slots [0, cursor) are final
         self.launched = 0          # elements [0, launched) already handed to all_reduce
@@ -125,6 +148,15 @@ class GradientBucketer:
                 self._launch(self.launched, self.bucket_ends[self.next_bucket])
                 self.next_bucket += 1
 
+    def _reduce(self, chunk: torch.Tensor):
+        if self.wire_dtype is None:
+            self.handles.append(dist.all_reduce(chunk, group=self.pg, async_op=True))
+            return
+        wire = chunk.to(self.wire_dtype)
+        h = dist.all_reduce(wire, group=self.pg, async_op=True)
+        self.handles.append(h)
+        self._pending_wire.append((h, chunk, wire))
+
     def _launch(self, a: int, b: int):
         if b <= a:
             return
@@ -132,15 +164,20 @@ class GradientBucketer:
         if self.comm_stream is not None:
             self._comm_waits_for_compute()
             with torch.cuda.stream(self.comm_stream):
-                self.handles.append(dist.all_reduce(chunk, group=self.pg, async_op=True))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._reduce(chunk)
+                e1.record()
+                self.bucket_events.append((e0, e1, (b - a) * 4))
         else:
-            self.handles.append(dist.all_reduce(chunk, group=self.pg, async_op=True))
+            self._reduce(chunk)
         self.launched = b
 
     def finish(self, scalars: Optional[torch.Tensor] = None, sample_size_index: int = 1):
         """End of backward: reduce what is left, wait, scale by 1 / global sample size.
         ``scalars`` (fp32 vector: loss, sample_size, counters...) is summed over ranks in place."""
         if self.active:
+            self.bucket_events = self.bucket_events[-64:]
             if self.layout_final:
                 while self.next_bucket < len(self.bucket_ends):     # buckets whose parameters never reported
                     self._launch(self.launched, self.bucket_ends[self.next_bucket])
@@ -152,6 +189,12 @@ class GradientBucketer:
                                     else self._scalar_reduce(scalars))
             for h in self.handles:
                 h.wait()
+            for _, chunk, wire in self._pending_wire:       # reduced low-precision copies back into the fp32 arena
+                if self.comm_stream is not None:
+                    with torch.cuda.stream(self.comm_stream):
+                        chunk.copy_(wire)
+                else:
+                    chunk.copy_(wire)
             if self.comm_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
         if scalars is not None:
@@ -174,13 +217,16 @@ class GradientBucketer:
 class DataParallel:
     """Wrap a ``GraphormerModel`` for one-process-per-GPU data parallelism."""
 
-    def __init__(self, model, bucket_mb: int = 64, process_group=None):
+    def __init__(self, model, bucket_mb: int = 64, process_group=None, wire_dtype: Optional[torch.dtype] = None):
+        import os
         self.model = model
         flat = model.prepare_main_grads()
         ge = model.encoder.graph_encoder
         params = [p for p in model.parameters() if p.requires_grad and hasattr(p, "main_grad")]
         stream = torch.cuda.Stream() if flat.is_cuda else None
-        self.bucketer = GradientBucketer(params, flat, bucket_mb << 20, process_group, stream)
+        if wire_dtype is None and os.environ.get("MDT_DDP_WIRE", "").lower() in ("bf16", "bfloat16"):
+            wire_dtype = torch.bfloat16
+        self.bucketer = GradientBucketer(params, flat, bucket_mb << 20, process_group, stream, wire_dtype=wire_dtype)
         # RCCL's kernels run beside backward and take whole CUs (a ping-pong GEMM workgroup leaves no LDS for a neighbour).
         # The persistent GEMM's STATIC tile walk assumes one resident workgroup per CU: a workgroup whose CU is busy
         # elsewhere starts late and finishes its statically assigned tiles late.  Its dynamic tile queue
@@ -208,7 +254,48 @@ class DataParallel:
         if not self.bucketer.layout_final:
             self.bucketer.finalize_layout()       # after the first backward: completion-ordered buckets
 
-    def broadcast_parameters(self, src: int = 0):
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            for p in self.model.parameters():
-                dist.broadcast(p.data, src)
+    def broadcast_parameters(self, src: int = 0, chunk_bytes: int = 256 << 20):
+        """Rank ``src``'s parameters and buffers to everyone: a few large flat broadcasts (one per dtype and per
+        ``chunk_bytes``) instead of one collective per tensor (~660 tensors at the launch configuration)."""
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        seen, groups = set(), {}
+        for t in list(self.model.parameters()) + list(self.model.buffers()):
+            if id(t) in seen:
+                continue
+            seen.add(id(t))
+            groups.setdefault(t.dtype, []).append(t.data)
+        self.broadcast_calls = 0
+        for dtype, ts in groups.items():
+            batch, size = [], 0
+            for t in ts + [None]:
+                if t is not None and (not batch or size + t.numel() * t.element_size() <= chunk_bytes):
+                    batch.append(t)
+                    size += t.numel() * t.element_size()
+                    continue
+                flat = torch.cat([b.reshape(-1) for b in batch])
+                dist.broadcast(flat, src, group=self.bucketer.pg)
+                self.broadcast_calls += 1
+                off = 0
+                for b in batch:
+                    b.copy_(flat[off:off + b.numel()].view(b.shape))
+                    off += b.numel()
+                batch, size = ([t], t.numel() * t.element_size()) if t is not None else ([], 0)
+
+    def diagnostics(self) -> dict:
+        """What the first multi-GPU run should print about itself (bench.py puts it into its JSON line)."""
+        b = self.bucketer
+        ev = [(e0, e1, n) for (e0, e1, n) in b.bucket_events]
+        times = []
+        for e0, e1, n in ev:
+            try:
+                e1.synchronize()
+                times.append(round(e0.elapsed_time(e1), 3))
+            except RuntimeError:
+                pass
+        ends = b.bucket_ends or [b.flat.numel()]
+        sizes = [round((e - s) * 4 / 2 ** 20, 1) for s, e in zip([0] + ends[:-1], ends)]
+        return dict(arena_mb=round(b.flat.numel() * 4 / 2 ** 20, 1), buckets=len(ends), bucket_mb=sizes,
+                    wire_dtype=str(b.wire_dtype or torch.float32).replace("torch.", ""), layout_final=bool(b.layout_final),
+                    collective_issue_ms_recent=times[-len(ends):], steps=self._steps,
+                    broadcast_calls=getattr(self, "broadcast_calls", 0))

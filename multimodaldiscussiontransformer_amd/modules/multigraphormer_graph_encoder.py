@@ -319,6 +319,16 @@ class MultiGraphormerGraphEncoder(nn.Module):
             E.rows_mix(tape, x, text, M, alpha=1.0, beta=0.0, d_idx=pb.graph_row, s_idx=rows["bn0_rows"])
         x = self.layers[-1]._fwd(tape, x, gspec)       # layers[F]; layers[F-1] is never executed (quirk 3)
         glob = E.take_rows(tape, x, B, s_map=(1, T, 0))
+        if I == 0 and tape.on_params_ready is not None and not tape.inference:
+            # a batch without any image comment: the ViT side never runs, so its parameters would never be reported to the
+            # gradient exchange and every bucket behind them would wait for the end of backward — on ALL ranks, since
+            # collectives are matched.  Their gradients are the zeros already in the arena: report them first thing in
+            # backward (the last entry recorded is the first one the backward walk reaches).
+            image_side = [p for p in self.vit_model.parameters()]
+            for st in self.fusion_layers:
+                for fl in st.fusion_layers:
+                    image_side += list(fl.vit_encoder.parameters())
+            tape.record(lambda: tape.on_params_ready(image_side))
         return text, glob, rows
 
     def _prune_indices(self, pb: PackedBatch, ix):

@@ -44,6 +44,7 @@ def make_tree(
     image_size: int = 224,
     shape: str = "bushy",
     min_len: int = 8,
+    image_pool: "np.ndarray | None" = None,
 ) -> dict:
     parent = bushy_parents(n_nodes) if shape == "bushy" else deep_thread_parents(n_nodes, rng)
     lo = min(1000, max(1, vocab_size // 8))
@@ -58,7 +59,11 @@ def make_tree(
     images = None
     if n_img > 0:
         image_index[rng.choice(n_nodes, size=n_img, replace=False)] = True
-        images = rng.standard_normal((n_img, 3, image_size, image_size), dtype=np.float32)
+        if image_pool is None:
+            images = rng.standard_normal((n_img, 3, image_size, image_size), dtype=np.float32)
+        else:       # a window of a shared pool of random images at a random offset: a VIEW (no host copy), different per tree
+            o = int(rng.integers(0, image_pool.shape[0] - n_img + 1))
+            images = image_pool[o:o + n_img]
     y_mask = np.zeros(n_nodes, dtype=bool)
     y_mask[int(rng.integers(0, n_nodes))] = True
     y = np.asarray([1.0 if rng.random() < 0.3 else 0.0], dtype=np.float32)

@@ -106,3 +106,92 @@ def test_relayout_preserves_gradients_single_process():
     for i, p in enumerate(params):
         assert torch.all(p.main_grad == float(i + 1))
         assert p.main_grad.data_ptr() >= flat.data_ptr()
+
+
+def test_balance_trees_by_token_cost():
+    """greedy assignment by N_i (L + nb) + I_i (P + nb).  Skewed image fractions: dealing trees round-robin
+    leaves one rank with most of the image work; the balanced deal is within a few per cent."""
+    from multimodaldiscussiontransformer_amd.ddp import balance_trees
+    import numpy as np
+    rng = np.random.default_rng(3)
+    n = rng.integers(32, 65, size=64).tolist()
+    img = [int(k * f) for k, f in zip(n, np.where(np.arange(64) % 8 == 0, 0.9, 0.05))]      # every 8th tree is image-heavy
+    cost = [a * 104 + b * 201 for a, b in zip(n, img)]
+    world = 8
+    share = balance_trees(n, img, world)
+    assert sorted(k for sh in share for k in sh) == list(range(64)) and all(sh == sorted(sh) for sh in share)
+    load = [sum(cost[k] for k in sh) for sh in share]
+    naive = [sum(cost[k] for k in range(r, 64, world)) for r in range(world)]
+    assert max(load) / (sum(load) / world) < 1.03, load
+    assert max(naive) / (sum(naive) / world) > 1.5, naive          # what seeding trees by rank would have done here
+    assert balance_trees(n, img, world) == share                      # deterministic: every rank computes the same deal
+    assert balance_trees([5], [0], 2) == [[0], []]
+    eq = balance_trees([10] * 6, [0] * 6, 3)
+    assert [len(s) for s in eq] == [2, 2, 2]
+
+
+def _worker_wire_and_broadcast(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multimodaldiscussiontransformer_amd.ddp import DataParallel, GradientBucketer
+        # (a) bf16 on the wire: each bucket travels as a bf16 copy and comes back into the fp32 arena
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in ((40, 8), (8,), (64, 4))]
+        flat = torch.zeros(sum(p.numel() for p in params))
+        b = GradientBucketer(params, flat, bucket_bytes=4 * 300, wire_dtype=torch.bfloat16)
+        for step in range(2):
+            flat.zero_()
+            for i, p in enumerate(params):
+                p.main_grad.fill_(0.5 * (i + 1) * (rank + 1))            # exactly representable in bf16
+            for p in params:
+                b.on_params_ready([p])
+            b.finish(torch.tensor([0.0, 1.0, 0, 0, 0, 0]))
+            if not b.layout_final:
+                b.finalize_layout()
+            for i, p in enumerate(params):
+                want = 0.5 * (i + 1) * sum(r + 1 for r in range(world)) / world
+                assert torch.all(p.main_grad == want), (i, float(p.main_grad.flatten()[0]), want)
+            assert flat.dtype == torch.float32
+        # (b) the REAL model through DataParallel: one flat broadcast per dtype / chunk makes every rank equal to rank 0
+        from types import SimpleNamespace
+        from multimodaldiscussiontransformer_amd.models import GraphormerModel
+        tiny = dict(dim=128, layers=4, heads=4, intermediate=128)
+        args = SimpleNamespace(num_bottleneck_tokens=2, num_fusion_layers=1, encoder_embed_dim=128, encoder_ffn_embed_dim=128,
+                               encoder_attention_heads=4, dropout=0.0, attention_dropout=0.0, act_dropout=0.0,
+                               bert_config=dict(tiny, vocab=512, max_pos=32, type_vocab=2), vit_config=dict(tiny, image_size=32, patch=16))
+        torch.manual_seed(1000 + rank)                                  # different weights on every rank
+        model = GraphormerModel.build_model(args, task=None)
+        dp = DataParallel(model, bucket_mb=1)
+        before = model.encoder.graph_encoder.bottle_neck.weight.detach().clone()
+        dp.broadcast_parameters()
+        n_tensors = len({id(t) for t in list(model.parameters()) + list(model.buffers())})
+        assert 1 <= dp.broadcast_calls <= 3 and n_tensors > 100, (dp.broadcast_calls, n_tensors)
+        digest = torch.stack([p.detach().double().sum() for p in model.parameters()])
+        both = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(both, digest)
+        assert torch.equal(both[0], both[1])
+        if rank == 1:
+            assert not torch.equal(before, model.encoder.graph_encoder.bottle_neck.weight.detach())
+        d = dp.diagnostics()
+        assert d["arena_mb"] > 1 and d["wire_dtype"] == "float32" and d["broadcast_calls"] == dp.broadcast_calls
+        q.put((rank, "ok", 0))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_wire_and_flat_broadcast_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_wire_and_broadcast, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info in out:
+        assert status == "ok", f"rank {rank}: {info}"

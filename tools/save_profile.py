@@ -13,6 +13,19 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = os.path.join(root, "gpurun_out", "")
 dst = os.path.join(root, "profiles", f"{rnd}_{tag}")
 shutil.copy(glob.glob(base + f"{tag}_prof/*/*kernel_stats.csv")[0], dst + "_kernel_stats.csv")
+def steps_in(stats_csv):
+    """steps in a kernel trace = launches of a kernel that runs exactly once per step (vit_patchify; bert_embed_rows
+    for a text-only run)"""
+    for r in csv.DictReader(open(stats_csv)):
+        if "vit_patchify" in r["Name"] or "bert_embed_rows" in r["Name"]:
+            return int(r["Calls"])
+    return None
+
+
+json.dump({"steps_in_trace": steps_in(dst + "_kernel_stats.csv"),
+           "note": "divide the TotalDurationNs of a kernel by steps_in_trace for its time per step; the trace covers warm-up, "
+                   "timed and roofline-pass steps of the profiled command alike"},
+          open(dst + "_kernel_stats_meta.json", "w"), indent=1)
 two = glob.glob(base + f"{tag}_prof2/*/*kernel_stats.csv")
 if two:
     shutil.copy(two[0], dst + "_kernel_stats_two_streams.csv")
