@@ -21,7 +21,8 @@ launch's rates (0.4 / 0.3 / 0.3; --dropout 0 ... turns it off).  Weak scaling: e
 Rank 0 prints ONE JSON line (contract in the task description) carrying
   value / ms_per_step   all comments of the timed steps / wall time between the two barrier + synchronize brackets
   ms_per_step_median    median over the timed steps of the per-step time (HIP events at the step boundaries)
-  packer_h2d_ms         copy-stream time per batch (pack + H2D + index build) — overlapped with the previous step
+  packer_h2d_ms         [median, max] copy-stream time per batch (pack + H2D + index build) over the timed steps —
+                        overlapped with the previous step; packer_host_ms the same for the host side alone
   roofline      the dominant kernel (bf16 MFMA tile GEMM): algorithmic FLOPs of its launches / their summed duration,
                 measured live with HIP events on the launch stream in a pass of the same steps on ONE stream right
                 after the timed region (the timed region overlaps the text and image branches on two HIP streams,
@@ -558,8 +559,9 @@ def main():
     t_issue = time.perf_counter() - t1
     fence()
     host_phases = {b[0]: round((b[1] - a[1]) * 1e3, 2) for a, b in zip(host_marks, host_marks[1:])}
-    packer_ms = round(pf.copy_ms_per_batch(), 2) if pf is not None else None
-    packer_host_ms = round(pf.stats["pack_host_s"] / max(1, pf.stats["batches"]) * 1e3, 2) if pf is not None else None
+    # per-batch cost of the feed (steady state: the warm-up batches pay the one-off pinned-memory allocations)
+    packer_ms = [round(x, 2) for x in pf.copy_ms_per_batch(skip=args.warmup)] if pf is not None else None
+    packer_host_ms = [round(x, 2) for x in pf.host_ms_per_batch(skip=args.warmup)] if pf is not None else None
     # roofline pass, after the timed region: the same kind of steps on ONE HIP stream with a HIP-event bracket around
     # every GEMM launch.  In the timed region the text and image branches run on two streams and their kernels overlap,
     # so a bracket there times "this kernel plus its wait for compute units held by the other branch", not the kernel.

@@ -50,9 +50,11 @@ class Prefetcher:
         self.items, self.make_batch, self.warm = items, make_batch, warm
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
+        if self.cuda and self.device.index is None:      # the worker thread must target the creator's CURRENT device
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
         self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
-        self.stats = dict(batches=0, pack_host_s=0.0, copy_ms=0.0)
+        self.stats = dict(batches=0, pack_host_s=0.0, host_s=[])
         self._timing = []
         self._err = None
         self._th = threading.Thread(target=self._run, name="mdt-prefetch", daemon=True)
@@ -103,13 +105,22 @@ class Prefetcher:
             self._timing.append((s, e))
         self.stats["batches"] += 1
         self.stats["pack_host_s"] += host_s
+        self.stats["host_s"].append(host_s)
         return b
 
-    def copy_ms_per_batch(self) -> float:
-        """Mean copy-stream time (pack + H2D + index build) per batch; synchronises the recorded events."""
-        tot, n = 0.0, 0
-        for s, e in self._timing:
+    def copy_ms_per_batch(self, skip: int = 0):
+        """(median, max) copy-stream time per batch — host packing between the two events included, H2D and index build —
+        over the batches handed out so far, the first ``skip`` left out (they pay the one-off pinned-memory
+        allocations); synchronises the recorded events."""
+        ts = []
+        for s, e in self._timing[skip:]:
             e.synchronize()
-            tot += s.elapsed_time(e)
-            n += 1
-        return tot / n if n else 0.0
+            ts.append(s.elapsed_time(e))
+        if not ts:
+            return 0.0, 0.0
+        ts.sort()
+        return ts[len(ts) // 2], ts[-1]
+
+    def host_ms_per_batch(self, skip: int = 0):
+        ts = sorted(self.stats["host_s"][skip:])
+        return (ts[len(ts) // 2] * 1e3, ts[-1] * 1e3) if ts else (0.0, 0.0)
