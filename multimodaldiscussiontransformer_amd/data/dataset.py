@@ -169,11 +169,12 @@ class BatchedDataDataset(FairseqDataset):
     """Batches trees with the native packer.  ``device``: where ``collater`` leaves the batch — "cpu" inside DataLoader
     workers (FairSeq moves the sample to the GPU), "cuda" when the trainer collates on the main process."""
 
-    def __init__(self, dataset, spatial_pos_max: int = 1024, device: str = "cpu"):
+    def __init__(self, dataset, spatial_pos_max: int = 1024, device: str = "cpu", sample_filter=None):
         super().__init__()
         self.dataset = dataset
         self.spatial_pos_max = spatial_pos_max
         self.device = device
+        self.sample_filter = sample_filter       # e.g. Task.filter_oversized
 
     def __getitem__(self, index):
         return self.dataset[int(index)]
@@ -183,6 +184,8 @@ class BatchedDataDataset(FairseqDataset):
 
     def _pack(self, samples: List[dict]):
         samples = [s for s in samples if s is not None]
+        if self.sample_filter is not None:
+            samples = self.sample_filter(samples)
         return samples, pack_batch(samples, self.spatial_pos_max, device=self.device).batched_data
 
     def collater(self, samples):

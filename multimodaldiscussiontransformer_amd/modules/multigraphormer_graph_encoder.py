@@ -235,6 +235,7 @@ class MultiGraphormerGraphEncoder(nn.Module):
         ``_indices``, or — ``prune_last``, the logits path — the compact [2M, D] output of a last fusion layer that
         computed only those two rows per comment (engine.transformer_block ``keep_rows``)."""
         tr = self.training
+        self.check_sequence_limits(pb)                       # before any kernel is enqueued
         p_emb = self.activation_dropout_p if tr else 0.0     # HF hidden_dropout_prob := act_dropout (:238,:243)
         nb = self.num_bottle_neck
         ix = self._indices(pb)
@@ -330,6 +331,24 @@ class MultiGraphormerGraphEncoder(nn.Module):
                     image_side += list(fl.vit_encoder.parameters())
             tape.record(lambda: tape.on_params_ready(image_side))
         return text, glob, rows
+
+    MAX_ATTENTION_TOKENS = 272      # one workgroup holds a whole (sequence, head) in LDS / registers (csrc/attention*.hip)
+
+    def check_sequence_limits(self, pb: PackedBatch):
+        """The attention kernels are single-pass over at most 272 tokens: 271 comments per discussion tree (+ the graph
+        token), nb + L text tokens, nb + P image tokens.  The reference has no such limit (--max-nodes 10000 is declared
+        and never enforced, tasks/task.py:41-44); a batch beyond it is refused HERE, with the numbers, instead of failing
+        inside forward after half the step was enqueued."""
+        lim = self.MAX_ATTENTION_TOKENS
+        nb = self.num_bottle_neck
+        npatch = (self.vit_config["image_size"] // self.vit_config["patch"]) ** 2 + 1
+        if pb.T > lim:
+            raise ValueError(f"a discussion tree of this batch has {pb.N} comments: graph attention handles at most {lim - 1} "
+                             f"per tree (set --max-nodes {lim - 1} / prune the tree as Pre-Processing/3-prune-trees.py does)")
+        if nb + pb.L > lim:
+            raise ValueError(f"{nb} bottleneck + {pb.L} text tokens per comment exceed the {lim}-token attention limit")
+        if pb.I > 0 and nb + npatch > lim:
+            raise ValueError(f"{nb} bottleneck + {npatch} image tokens exceed the {lim}-token attention limit")
 
     def _prune_indices(self, pb: PackedBatch, ix):
         key = ("prune_idx", self.num_bottle_neck, bool(self.ragged_tokens))
