@@ -226,6 +226,25 @@ int mdt_node_ce(void* stream, int dtype, int64_t M, int nlab, const void* logits
                 const int32_t* targets, float w_neg, float w_pos, int fp16_loss, float grad_scale,
                 float* out_loss, int32_t* counters, void* dlogits);
 
+/* ------------------------------------------------------------------ fp8 operands (BASELINE.json configs[4])
+ * Per-tensor-scaled OCP fp8 for the big k-contiguous GEMMs of the encoder blocks (every nn.Linear forward and, against a
+ * transposed weight copy, every input gradient): C[M,N] (bf16) = epilogue((1/scale_a)(1/scale_b) * A[M,K] B[N,K]^T), A in
+ * e4m3 (a_format 0: activations) or e5m2 (1: gradients), B in e4m3, fp32 accumulation on v_mfma_f32_16x16x32_{fp8,bf8}_fp8,
+ * same epilogues as mdt_gemm (bf16 store forms).  inv_scale_a / inv_scale_b are DEVICE floats (delayed scaling keeps
+ * every scale on the device).  Returns MDT_ERR_UNSUPPORTED for shapes the 8-bit kernel is not built for (N % 256, K % 64,
+ * K < 256, unaligned rows): the caller then stays in bf16. */
+int mdt_gemm_fp8(void* stream, int a_format, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                 int64_t ldb, void* C, int64_t ldc, int epilogue, const float* inv_scale_a, const float* inv_scale_b,
+                 const void* bias, const void* residual, int64_t ldr, void* aux, int64_t ldaux, float drop_p,
+                 uint64_t drop_seed, float* colsum);
+/* dst u8[rows, cols] = saturate_fp8(src * *scale_dev) (fmt 0: e4m3, |x| <= 448; 1: e5m2, |x| <= 57344; scale_dev NULL: 1);
+ * *amax_dev = max(*amax_dev, max |src|) (NULL: not tracked) — the input of the next step's scale. */
+int mdt_fp8_quantize(void* stream, int src_dtype, int fmt, int64_t rows, int64_t cols, const void* src, int64_t ld_src,
+                     void* dst, int64_t ld_dst, const float* scale_dev, float* amax_dev);
+/* Delayed scaling, all sites at once: scale[i] = fmt_max[i] / (amax[i] * margin), inv_scale[i] = 1 / scale[i] for every
+ * site whose amax is positive and finite (others keep their scale); amax[i] = 0. */
+int mdt_fp8_scale_update(void* stream, int n, float* amax, float* scale, float* inv_scale, const float* fmt_max, float margin);
+
 /* Community-contrastive loss on the global discussion embeddings (criterions/contrastive_loss.py:76-180):
  * emb T[B, D] (row stride ld), y / hard_y f32[B] (community label of every tree and of its polar-opposite community);
  * sim = scale * normalize(emb) normalize(emb)^T, weighted BCE against [y_i == y_j] with the reference's soft-negative

@@ -28,6 +28,8 @@ struct GemmParams {
   const void* B; int64_t ldb;
   void* C; int64_t ldc;
   int epilogue; float alpha;
+  const float* alpha_dev;       // fp8 path: the dequantisation factors 1 / scale_a and 1 / scale_b live on the device
+  const float* alpha_dev2;      //           (delayed scaling: no host sync); the output is scaled by their product
   const void* bias; const void* residual; int64_t ldr;
   void* aux; int64_t ldaux;
   int split_k; int64_t k_chunk;
@@ -896,11 +898,25 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
 // launch / drain that a 12-step (K = 768) tile pays per tile otherwise are gone.  At a boundary the early
 // group takes one extra barrier so both groups run their epilogues at the same time, and the stagger is
 // re-created on entry to the next tile.  bf16 output, split_k == 1, at least PP_DIST steps per tile.
-template <bool A_KM, bool B_KM, int PP_DIST, int EPK = -1>
+// F8 != 0: 8-bit operands (OCP e4m3 / e5m2), both k-contiguous.  A ring stage is the same 64-byte-row image — now 64 k deep —
+// and a 16-byte fragment read holds TWO K = 32 operands (bytes 0-7 and 8-15 of the lane's chunk: the k order inside a stage
+// is permuted the same way for both operands, which a contraction does not see), so a step issues 64
+// v_mfma_f32_16x16x32_{fp8,bf8}_fp8 per wave on half the bytes per flop.  F8 = 1: activations e4m3, 2: e5m2 (gradients);
+// weights e4m3.  The output is scaled by *alpha_dev = 1 / (scale_a * scale_b).
+typedef __attribute__((ext_vector_type(2))) long i64x2;
+template <int F8>
+__device__ __forceinline__ f32x4 mfma_f8(long w, long x, f32x4 c) {      // w: weight operand (e4m3), x: activation operand
+  if constexpr (F8 == 2) return __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(w, x, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w, x, c, 0, 0, 0);
+}
+
+template <bool A_KM, bool B_KM, int PP_DIST, int EPK = -1, int F8 = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
+  static_assert(F8 == 0 || (!A_KM && !B_KM), "8-bit operands are k-contiguous");
   constexpr int PP_NB = pp_nb(PP_DIST);
   constexpr int BM = 256, BN = 256;
   constexpr int A_BYTES = BM * 64;
+  constexpr int ESZ = F8 ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -908,8 +924,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
   const int wr = wave >> 2, wc = wave & 3;
   const bool late = wave >= 4;
   const int nvt = p.tiles_m * p.tiles_n;
-  const int nhs = 2 * (int)((p.K + T_BK - 1) / T_BK);
-  const int64_t lda_b = p.lda * 2, ldb_b = p.ldb * 2;
+  const int nhs = (int)((p.K * ESZ + 63) / 64);           // 64-byte steps
+  const int64_t lda_b = p.lda * ESZ, ldb_b = p.ldb * ESZ;
 
   struct Desc { __amdgpu_buffer_rsrc_t rsA, rsB; int a_col0, b_col0; int64_t m0, n0; };
   auto make_desc = [&](int v) {
@@ -1036,10 +1052,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
+      if constexpr (F8 == 0) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(b[j], a[i], acc[i][j]);
+          for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(b[j], a[i], acc[i][j]);
+      } else {
+#pragma unroll
+        for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[i][j] = mfma_f8<F8>(__builtin_bit_cast(i64x2, b[j])[hk], __builtin_bit_cast(i64x2, a[i])[hk], acc[i][j]);
+      }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -1051,7 +1077,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
     if (p.stamps) { s_cyc += __builtin_amdgcn_s_memtime() - t_cyc; s_real += __builtin_amdgcn_s_memrealtime() - t_real; s_nk += nhs / 2; }
     int popped = -1;
     if (dyn && has_next && tid == 0) popped = pop_tile();       // the tile after next; returns while the epilogue runs
-    direct_epilogue<2, EPK>(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 64);
+    if constexpr (F8 != 0) {
+      GemmParams pe = p;
+      pe.alpha = *p.alpha_dev * *p.alpha_dev2;
+      direct_epilogue<2, EPK>(pe, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 64);
+    } else {
+      direct_epilogue<2, EPK>(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 64);
+    }
     if (!has_next) break;
     cur = nxt;
     if (dyn) {
@@ -1411,6 +1443,57 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   return check_launch("gemm_bf16_pp256");
 }
 
+// 8-bit operands: persistent kernel only (large problems), NN layout only.
+template <int F8>
+static int launch_pp256p_f8(hipStream_t st, const GemmParams& p_in) {
+  GemmParams p = p_in;
+  // one workgroup per CU walks the tiles; a problem with fewer tiles than CUs gets one workgroup per tile (the tile
+  // order stays a bijection for any tile count, the walk just ends after the first tile)
+  const int nvt = p.tiles_m * p.tiles_n;
+  dim3 grid((unsigned)(nvt < num_cus() ? nvt : num_cus()), 1, 1);
+  p.tile_queue = nullptr;
+  p.stamps = nullptr;
+  p.group_n = p.tiles_n;
+  {
+    const double b_panel = 256.0 * (double)p.K;      // bytes: one byte per element
+    if (p.tiles_n % 2 == 0 && b_panel * p.tiles_n > 3.5e6 && b_panel * (p.tiles_n / 2) <= 2.5e6 &&
+        (double)p.tiles_m * p.tiles_n >= 4.0 * num_cus())
+      p.group_n = p.tiles_n / 2;
+  }
+  const size_t lds = (size_t)pp_nb(4) * PP_STAGE;
+#define LF8(E_)                                                                                              \
+  {                                                                                                          \
+    auto kern = gemm_bf16_pp256p<false, false, 4, E_, F8>;                                                   \
+    static bool attr_set = false;                                                                            \
+    if (!attr_set) {                                                                                         \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+        (void)hipGetLastError();                                                                             \
+        set_error("gemm_fp8: cannot reserve %zu bytes of LDS", lds);                                         \
+        return MDT_ERR_LAUNCH;                                                                               \
+      }                                                                                                      \
+      attr_set = true;                                                                                       \
+    }                                                                                                        \
+    hipLaunchKernelGGL(kern, grid, 512, lds, st, p);                                                         \
+  }
+  constexpr int E_BIAS = MDT_EPI_BIAS, E_DENSE = MDT_EPI_BIAS | MDT_EPI_RESIDUAL | MDT_EPI_DROPOUT,
+                E_FC1 = MDT_EPI_BIAS | MDT_EPI_GELU | MDT_EPI_AUX_GRAD, E_RES = MDT_EPI_RESIDUAL,
+                E_DFC2 = MDT_EPI_MULAUX | MDT_EPI_COLSUM;
+  const int e = p.epilogue;
+  if constexpr (F8 == 1) {          // forward: activations e4m3
+    if (e == E_BIAS) LF8(E_BIAS)
+    else if (e == E_DENSE) LF8(E_DENSE)
+    else if (e == E_FC1 && p.aux) LF8(E_FC1)
+    else LF8(-1)
+  } else {                          // input gradients: dY e5m2 against the transposed e4m3 weight copy
+    if (e == 0) LF8(0)
+    else if (e == E_RES) LF8(E_RES)
+    else if (e == E_DFC2) LF8(E_DFC2)
+    else LF8(-1)
+  }
+#undef LF8
+  return check_launch("gemm_fp8_pp256p");
+}
+
 }  // namespace mdt
 
 using namespace mdt;
@@ -1445,6 +1528,7 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   p.colsum = colsum;
   p.stamps = nullptr;
   p.tile_queue = nullptr;
+  p.alpha_dev = p.alpha_dev2 = nullptr;
   p.group_n = 1 << 30;   // row-major unless launch_pp256 decides otherwise
   if (const char* dg = getenv("MDT_GEMM_DIAG")) p.epilogue |= atoi(dg) << 20;   // 1: skip stores, 2: sc1 stores (direct epilogue only)
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_COLSUM) || (colsum && split_k == 1), "mdt_gemm: MDT_EPI_COLSUM needs a colsum buffer and split_k == 1");
@@ -1511,6 +1595,39 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   if (dtype == MDT_F32) return launch_generic<float, float>(st, p, trans_a, trans_b);
   return out_dtype == MDT_F32 ? launch_generic<bf16_t, float>(st, p, trans_a, trans_b)
                               : launch_generic<bf16_t, bf16_t>(st, p, trans_a, trans_b);
+}
+
+extern "C" int mdt_gemm_fp8(void* stream, int a_format, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                            const void* B, int64_t ldb, void* C, int64_t ldc, int epilogue, const float* inv_scale_a,
+                            const float* inv_scale_b, const void* bias, const void* residual, int64_t ldr, void* aux,
+                            int64_t ldaux, float drop_p, uint64_t drop_seed, float* colsum) {
+  MDT_CHECK_ARG(a_format == 0 || a_format == 1, "mdt_gemm_fp8: a_format %d (0 = e4m3, 1 = e5m2)", a_format);
+  MDT_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "mdt_gemm_fp8: negative shape");
+  if (M == 0 || N == 0) return MDT_OK;
+  MDT_CHECK_ARG(A && B && C && inv_scale_a && inv_scale_b, "mdt_gemm_fp8: null operand / scale");
+  MDT_CHECK_ARG(!(epilogue & MDT_EPI_BIAS) || bias, "mdt_gemm_fp8: MDT_EPI_BIAS without bias");
+  MDT_CHECK_ARG(!(epilogue & MDT_EPI_RESIDUAL) || residual, "mdt_gemm_fp8: MDT_EPI_RESIDUAL without residual");
+  MDT_CHECK_ARG(!(epilogue & (MDT_EPI_DGELU | MDT_EPI_MULAUX)) || aux, "mdt_gemm_fp8: MDT_EPI_DGELU / MDT_EPI_MULAUX without aux");
+  MDT_CHECK_ARG(!(epilogue & MDT_EPI_AUX_GRAD) || (epilogue & MDT_EPI_GELU), "mdt_gemm_fp8: MDT_EPI_AUX_GRAD needs MDT_EPI_GELU");
+  MDT_CHECK_ARG(!(epilogue & (MDT_EPI_ATOMIC | MDT_EPI_ACCUM)), "mdt_gemm_fp8: bf16 store epilogues only");
+  MDT_CHECK_ARG(!(epilogue & MDT_EPI_COLSUM) || colsum, "mdt_gemm_fp8: MDT_EPI_COLSUM needs a colsum buffer");
+  MDT_CHECK_ARG(!(epilogue & MDT_EPI_DROPOUT) || (drop_p >= 0.f && drop_p < 1.f && M * N < DROP_MAX_ELEMS), "mdt_gemm_fp8: bad dropout site");
+  // the 8-bit instantiation exists for the big k-contiguous GEMMs only: anything else is the caller's cue to stay in bf16
+  const bool ok = N % 256 == 0 && K % 64 == 0 && K >= 256 && lda % 16 == 0 && ldb % 16 == 0 && (((uintptr_t)A | (uintptr_t)B) % 16 == 0) &&
+                  ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && (!(epilogue & MDT_EPI_BIAS) || ((uintptr_t)bias & 15) == 0) &&
+                  (!(epilogue & MDT_EPI_RESIDUAL) || (ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0)) &&
+                  (!aux || (ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0)) && lda * 256 < (1ll << 31) && ldb * 256 < (1ll << 31);
+  if (!ok) MDT_UNSUPPORTED("mdt_gemm_fp8: shape M=%lld N=%lld K=%lld (needs N %% 256 == 0, K %% 64 == 0, K >= 256, 16-byte rows)",
+                           (long long)M, (long long)N, (long long)K);
+  GemmParams p;
+  p.M = M; p.N = N; p.K = K; p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+  p.epilogue = epilogue; p.alpha = 1.0f; p.alpha_dev = inv_scale_a; p.alpha_dev2 = inv_scale_b;
+  p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux; p.split_k = 1; p.k_chunk = K;
+  p.drop = make_drop((epilogue & MDT_EPI_DROPOUT) ? drop_p : 0.f, drop_seed);
+  p.colsum = colsum;
+  p.tiles_m = (int)((M + 255) / 256);
+  p.tiles_n = (int)(N / 256);
+  return a_format == 0 ? launch_pp256p_f8<1>((hipStream_t)stream, p) : launch_pp256p_f8<2>((hipStream_t)stream, p);
 }
 
 extern "C" int mdt_colsum(void* stream, int dtype, int64_t M, int64_t N, const void* X, int64_t ldx, float* out,

@@ -23,6 +23,7 @@ from typing import Callable, List, Optional, Sequence
 
 import torch
 
+from . import fp8 as F8
 from . import ops
 
 
@@ -192,6 +193,8 @@ class Tape:
             self._leave_side()
         self.ops = []
         self.sync_streams()
+        if F8.ACTIVE is not None:
+            F8.ACTIVE.end_of_step()          # this step's |x| maxima become the next step's scales (one launch)
 
     def sync_streams(self):
         """End of a pass: whatever follows on the main stream sees the side stream's work."""
@@ -321,25 +324,39 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         ops.row_axpby(full, R, di=keep_rows, a=g_)
         return full
 
+    f8 = F8.ACTIVE
+
+    def lin8(x_, w_, tag, **kw_):
+        """the 8-bit kernel where it pays (fp8.py) and the shape allows, else None"""
+        return None if f8 is None else f8.linear(x_, w_, (tag, id(w_)), **kw_)
+
     if not pre_ln:
-        qkv = ops.gemm(xd, P.qkv_w.data, bias=P.qkv_b.data)
+        qkv = lin8(xd, P.qkv_w, "qkv", bias=P.qkv_b.data)
+        if qkv is None:
+            qkv = ops.gemm(xd, P.qkv_w.data, bias=P.qkv_b.data)
         ctx_full, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw, **akw)
         ctx, xk = gather(ctx_full), gather(xd)
         t = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xk, drop_p=p_hidden, drop_seed=s_o)
         a, m1, r1 = ops.layernorm_fwd(t, P.ln1_w.data, P.ln1_b.data, eps)
         u = torch.empty(a.shape[0], P.fc1_w.shape[0], dtype=a.dtype, device=a.device)
-        h = ops.gemm(a, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act)
+        h = lin8(a, P.fc1_w, "fc1", bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act)
+        if h is None:
+            h = ops.gemm(a, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act)
         y = ops.gemm(h, P.fc2_w.data, bias=P.fc2_b.data, residual=a, drop_p=p_hidden, drop_seed=s_f2)
         out, m2, r2 = ops.layernorm_fwd(y, P.ln2_w.data, P.ln2_b.data, eps)
     else:
         n1, m1, r1 = ops.layernorm_fwd(xd, P.ln1_w.data, P.ln1_b.data, eps)
-        qkv = ops.gemm(n1, P.qkv_w.data, bias=P.qkv_b.data)
+        qkv = lin8(n1, P.qkv_w, "qkv", bias=P.qkv_b.data)
+        if qkv is None:
+            qkv = ops.gemm(n1, P.qkv_w.data, bias=P.qkv_b.data)
         ctx_full, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw, **akw)
         ctx, xk = gather(ctx_full), gather(xd)
         hmid = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xk, drop_p=p_hidden, drop_seed=s_o)
         n2, m2, r2 = ops.layernorm_fwd(hmid, P.ln2_w.data, P.ln2_b.data, eps)
         u = torch.empty(n2.shape[0], P.fc1_w.shape[0], dtype=n2.dtype, device=n2.device)
-        f = ops.gemm(n2, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act)
+        f = lin8(n2, P.fc1_w, "fc1", bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act)
+        if f is None:
+            f = ops.gemm(n2, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act)
         out = ops.gemm(f, P.fc2_w.data, bias=P.fc2_b.data, residual=hmid, drop_p=p_hidden, drop_seed=s_f2)
     o = Var(out)
 
@@ -367,8 +384,11 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         dy, dyd = _ln_bwd_dense(tape, g, y, P.ln2_w, P.ln2_b, m2, r2, P.fc2_b, p_hidden, s_f2)
         wgrad(tape, dyd, h, P.fc2_w, None)
         gb1 = tape.pgrad(P.fc1_b)           # fc1 bias gradient = colsum(du): fused into the GEMM epilogue
-        du = ops.gemm(dyd, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_MULAUX,
-                      colsum=None if gb1 is None else gb1.view(-1))
+        du = lin8(dyd, P.fc2_w, "d_fc2", transposed_weight=True, grad=True, aux=u, epilogue=ops.EPI_MULAUX,
+                  colsum=None if gb1 is None else gb1.view(-1))
+        if du is None:
+            du = ops.gemm(dyd, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_MULAUX,
+                          colsum=None if gb1 is None else gb1.view(-1))
         wgrad(tape, du, a, P.fc1_w, None)
         da = ops.gemm(du, P.fc1_w.data, trans_b=True, residual=dy)
         dt_, dtd = _ln_bwd_dense(tape, da, t, P.ln1_w, P.ln1_b, m1, r1, P.o_b, p_hidden, s_o)
@@ -389,8 +409,11 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         gd = hdrop(g, s_f2)
         wgrad(tape, gd, f, P.fc2_w, P.fc2_b)
         gb1 = tape.pgrad(P.fc1_b)
-        du = ops.gemm(gd, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_MULAUX,
-                      colsum=None if gb1 is None else gb1.view(-1))
+        du = lin8(gd, P.fc2_w, "d_fc2", transposed_weight=True, grad=True, aux=u, epilogue=ops.EPI_MULAUX,
+                  colsum=None if gb1 is None else gb1.view(-1))
+        if du is None:
+            du = ops.gemm(gd, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_MULAUX,
+                          colsum=None if gb1 is None else gb1.view(-1))
         wgrad(tape, du, n2, P.fc1_w, None)
         dn2 = ops.gemm(du, P.fc1_w.data, trans_b=True)
         dh, dhd = _ln_bwd_dense(tape, dn2, hmid, P.ln2_w, P.ln2_b, m2, r2, P.o_b, p_hidden, s_o, add=g)

@@ -109,6 +109,13 @@ class GraphormerModel(FairseqEncoderModel):
     def zero_main_grads(self):
         self.main_grad_flat.zero_()
 
+    def enable_fp8(self, on: bool = True):
+        """BASELINE.json configs[4]: per-tensor-scaled fp8 operands (e4m3 activations / weights, e5m2 gradients, delayed
+        scaling) for the encoder blocks' QKV and fc1 projections and fc2's input gradient (fp8.py says why those)."""
+        from .. import fp8
+        fp8.ACTIVE = fp8.Fp8State(next(self.parameters()).device) if on else None
+        return fp8.ACTIVE
+
 
 class GraphormerEncoder(FairseqEncoder):
     def __init__(self, args):

@@ -18,7 +18,7 @@ __all__ = [
     "bert_embed_rows",
     "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "graph_attn_bias",
     "row_axpby", "row_scatter_add", "bert_embed_sum", "vit_patchify", "vit_assemble", "graph_node_feature",
-    "tanh_fwd", "tanh_bwd", "node_ce", "contrastive_loss", "cast", "transpose2d", "dropout", "dropout_mask",
+    "tanh_fwd", "tanh_bwd", "node_ce", "contrastive_loss", "fp8_quantize", "fp8_scale_update", "gemm_fp8", "cast", "transpose2d", "dropout", "dropout_mask",
     "EPI_BIAS", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_ACCUM", "EPI_ATOMIC", "EPI_DROPOUT", "EPI_AUX_GRAD", "EPI_MULAUX",
 ]
 
@@ -281,6 +281,48 @@ def contrastive_loss(emb, y, hard_y, scale, soft_negative_weight, adaptive, *, g
                                    float(soft_negative_weight), int(bool(adaptive)), ptr(ws), float(grad_scale), ptr(loss),
                                    ptr(counters), ptr(d_emb), _2d(d_emb) if d_emb is not None else 0), "mdt_contrastive_loss")
     return loss, counters, d_emb
+
+
+FP8_E4M3, FP8_E5M2 = 0, 1
+FP8_MAX = {FP8_E4M3: 448.0, FP8_E5M2: 57344.0}
+
+
+def fp8_quantize(src: torch.Tensor, fmt: int = FP8_E4M3, scale: Optional[torch.Tensor] = None, amax: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """u8[rows, cols] = saturate_fp8(src * scale); ``scale`` / ``amax``: fp32 device scalars (1-element tensors or views)."""
+    rows, cols = src.shape
+    if out is None:
+        out = torch.empty(rows, cols, dtype=torch.uint8, device=src.device)
+    check(lib.mdt_fp8_quantize(stream(), dt(src), int(fmt), rows, cols, ptr(src), _2d(src), ptr(out), _2d(out), ptr(scale), ptr(amax)),
+          "mdt_fp8_quantize")
+    return out
+
+
+def fp8_scale_update(amax, scale, inv_scale, fmt_max, margin=1.0):
+    check(lib.mdt_fp8_scale_update(stream(), amax.numel(), ptr(amax), ptr(scale), ptr(inv_scale), ptr(fmt_max), float(margin)),
+          "mdt_fp8_scale_update")
+
+
+def gemm_fp8(a8: torch.Tensor, b8: torch.Tensor, inv_scale_a: torch.Tensor, inv_scale_b: torch.Tensor, *, a_format: int = FP8_E4M3,
+             out: Optional[torch.Tensor] = None, bias=None, residual=None, aux=None, epilogue=0, drop_p=0.0, drop_seed=0, colsum=None):
+    """out[M, N] (bf16) = epilogue(inv_scale_a * inv_scale_b * a8 @ b8^T); a8 u8[M, K] (e4m3 / e5m2), b8 u8[N, K] (e4m3)."""
+    M, K = a8.shape
+    N = b8.shape[0]
+    assert b8.shape[1] == K and a8.dtype == torch.uint8 and b8.dtype == torch.uint8
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a8.device)
+    if bias is not None:
+        epilogue |= EPI_BIAS
+    if residual is not None:
+        epilogue |= EPI_RESIDUAL
+    if drop_p > 0.0:
+        epilogue |= EPI_DROPOUT
+    if colsum is not None:
+        epilogue |= EPI_COLSUM
+    check(lib.mdt_gemm_fp8(stream(), int(a_format), M, N, K, ptr(a8), _2d(a8), ptr(b8), _2d(b8), ptr(out), _2d(out), epilogue,
+                           ptr(inv_scale_a), ptr(inv_scale_b), ptr(bias), ptr(residual), _2d(residual) if residual is not None else 0,
+                           ptr(aux), _2d(aux) if aux is not None else 0, float(drop_p), int(drop_seed), ptr(colsum)), "mdt_gemm_fp8")
+    return out
 
 
 def cast(src, dtype):

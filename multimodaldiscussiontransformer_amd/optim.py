@@ -69,6 +69,9 @@ class FusedAdam:
                                           float(self.weight_decay), self.step_count, ptr(grad_scale)), "mdt_adam_step_multi")
             done |= ids
         self._step_rest(lr, grad_scale, done)
+        from . import fp8
+        if fp8.ACTIVE is not None:
+            fp8.ACTIVE.optimizer_stepped()      # the cached 8-bit weight copies are stale now
 
     def _step_rest(self, lr, grad_scale, done):
         for p in self.params:
