@@ -22,7 +22,12 @@ import torch
 
 from . import ops
 
+import os
+
 MARGIN = 2.0
+# which GEMMs take the 8-bit kernel: any of "qkv", "fc1", "d_fc2" (MDT_FP8_SITES=fc1,d_fc2 leaves the QKV projection in bf16:
+# the softmax amplifies errors of q and k, see DESIGN.md for the measured trade)
+SITES = tuple(x for x in os.environ.get("MDT_FP8_SITES", "qkv,fc1,d_fc2").split(",") if x)
 
 
 class Fp8State:
@@ -94,7 +99,7 @@ class Fp8State:
         or None when the shape is not one it is built for (the caller then runs the bf16 GEMM)."""
         n_out = w.shape[1] if transposed_weight else w.shape[0]
         k = w.shape[0] if transposed_weight else w.shape[1]
-        if x.dtype != torch.bfloat16 or not self.eligible(x.shape[0], n_out, k):
+        if site[0] not in SITES or x.dtype != torch.bfloat16 or not self.eligible(x.shape[0], n_out, k):
             return None
         fmt = ops.FP8_E5M2 if grad else ops.FP8_E4M3
         x8, inv_x = self.quantize(x, site, fmt)
