@@ -160,6 +160,10 @@ typedef struct {
   float* d_virt;              /* f32[H], atomically accumulated, or NULL */
 } mdt_attn_bwd_args;
 int mdt_attention_bwd(void* stream, const mdt_attn_bwd_args* a);
+/* Head-averaged attention probabilities, fp32 [nseq, S, S] (modules/multihead_attention.py:205-214, need_weights=True):
+ * recomputed from the qkv buffer and the log-sum-exp mdt_attention_fwd wrote (same args struct; out / dropout fields are
+ * not read).  Masked keys give 0. */
+int mdt_attention_mean_probs(void* stream, const mdt_attn_fwd_args* a, float* out);
 
 /* Materialise the [nseq,H,S,S] structural bias (API parity with GraphAttnBias.forward,
  * modules/graphormer_layers.py:86-110); the fused encoder path never calls this. */

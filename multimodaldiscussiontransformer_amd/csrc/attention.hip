@@ -510,6 +510,33 @@ __global__ void graph_attn_bias_kernel(int nseq, int S, int H, const float* attn
   }
 }
 
+// Head-averaged attention probabilities (modules/multihead_attention.py:205-214, need_weights=True): recomputed from the
+// saved q, k and the forward's log-sum-exp — one thread per (sequence, query, key), looping over the heads.  Module-level
+// API only (the encoder layers pass need_weights=False); fp32 output [nseq, S, S], masked keys give 0.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_mean_probs_kernel(mdt_attn_fwd_args a, float* out) {
+  const int S = a.S, H = a.H, hd = a.hd;
+  const int64_t n = (int64_t)a.nseq * S * S;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int key = (int)(i % S), q = (int)((i / S) % S), seq = (int)(i / ((int64_t)S * S));
+    const T* qrow = (const T*)a.qkv + ((int64_t)seq * a.seq_stride + (int64_t)q * a.pos_stride) * a.ld_qkv;
+    const T* krow = (const T*)a.qkv + ((int64_t)seq * a.seq_stride + (int64_t)key * a.pos_stride) * a.ld_qkv + (int64_t)H * hd;
+    float acc = 0.f;
+    for (int h = 0; h < H; ++h) {
+      BiasCtx bc{seq, h, S, H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
+      float v = key_only_bias<T>(bc, key);
+      if (v == 0.f) {
+        float dot = 0.f;
+        for (int d = 0; d < hd; ++d) dot += to_f32(qrow[h * hd + d]) * to_f32(krow[h * hd + d]);
+        v = dot * a.scale + (a.attn_bias ? pair_bias<T, true>(bc, q, key) : pair_bias<T, false>(bc, q, key));
+        const float l = a.lse[((int64_t)seq * H + h) * S + q];
+        acc += (v == -INFINITY || l == -INFINITY) ? 0.f : __expf(v - l);
+      }
+    }
+    out[i] = acc / (float)H;
+  }
+}
+
 template <typename T, int HD, int NT, bool STRUCT, bool DROP>
 static int launch_fwd(hipStream_t st, const AttnParams& p) {
   constexpr int s_pad32 = (NT * 16 + 31) & ~31;
@@ -638,6 +665,18 @@ extern "C" int mdt_attention_bwd(void* stream, const mdt_attn_bwd_args* a) {
   p.dout = a->dout; p.ld_dout = a->ld_dout; p.dqkv = a->dqkv; p.ld_dqkv = a->ld_dqkv;
   p.d_dense_bias = a->d_dense_bias; p.d_sp_table = a->d_sp_table; p.d_virt = a->d_virt;
   return dispatch<true>((hipStream_t)stream, p);
+}
+
+extern "C" int mdt_attention_mean_probs(void* stream, const mdt_attn_fwd_args* a, float* out) {
+  MDT_CHECK_ARG(a && out, "attention_mean_probs: null args");
+  if (a->nseq == 0) return MDT_OK;
+  if (int e = check_args(*a)) return e;
+  MDT_CHECK_ARG(!a->seq_offsets, "attention_mean_probs: ragged sequences are not supported (module-level API only)");
+  const int64_t n = (int64_t)a->nseq * a->S * a->S;
+  const int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  if (a->dtype == MDT_F32) hipLaunchKernelGGL((attn_mean_probs_kernel<float>), grid, 256, 0, (hipStream_t)stream, *a, out);
+  else hipLaunchKernelGGL((attn_mean_probs_kernel<bf16_t>), grid, 256, 0, (hipStream_t)stream, *a, out);
+  return check_launch("attention_mean_probs");
 }
 
 extern "C" int mdt_graph_attn_bias(void* stream, int dtype, int nseq, int S, int H, const float* attn_bias,

@@ -434,13 +434,16 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
     return o
 
 
-def attention_layer(tape: Tape, x: Var, qkv_w, qkv_b, o_w, o_b, spec: AttnSpec, p_attn: float = 0.0) -> Var:
-    """Bare multi-head self-attention + output projection (modules/multihead_attention.py:91-214)."""
+def attention_layer(tape: Tape, x: Var, qkv_w, qkv_b, o_w, o_b, spec: AttnSpec, p_attn: float = 0.0, stash: Optional[dict] = None) -> Var:
+    """Bare multi-head self-attention + output projection (modules/multihead_attention.py:91-214).  ``stash``: receives
+    the qkv buffer and the log-sum-exp (what the need_weights=True path recomputes the probabilities from)."""
     xd = x.data
     kw = spec.kwargs()
     kw.update(drop_p=p_attn, drop_seed=tape.next_seed())
     qkv = ops.gemm(xd, qkv_w.data, bias=None if qkv_b is None else qkv_b.data)
     ctx, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw)
+    if stash is not None:
+        stash.update(qkv=qkv, lse=lse, kw=spec.kwargs())
     out = ops.gemm(ctx, o_w.data, bias=None if o_b is None else o_b.data)
     o = Var(out)
 

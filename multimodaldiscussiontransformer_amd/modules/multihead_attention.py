@@ -70,10 +70,10 @@ class MultiheadAttention(QKVFusedMixin, nn.Module):
             nn.init.constant_(self.out_proj.bias, 0.0)
 
     # tape-level ------------------------------------------------------------------------
-    def _fwd(self, tape, x: E.Var, spec: E.AttnSpec) -> E.Var:
+    def _fwd(self, tape, x: E.Var, spec: E.AttnSpec, stash=None) -> E.Var:
         p = self.dropout_p if self.training else 0.0
         return E.attention_layer(tape, x, self.qkv_weight, self.qkv_bias, self.out_proj.weight, self.out_proj.bias, spec,
-                                 p_attn=p)
+                                 p_attn=p, stash=stash)
 
     # public (reference signature) ------------------------------------------------------
     def forward(self, query, key: Optional[Tensor], value: Optional[Tensor], attn_bias: Optional[Tensor],
@@ -82,8 +82,7 @@ class MultiheadAttention(QKVFusedMixin, nn.Module):
         """Input shape: Time x Batch x Channel.  ``key`` / ``value`` are ignored exactly as in the
         reference (:134-136 project ``query`` three times)."""
         if need_head_weights or before_softmax or attn_mask is not None:
-            raise NotImplementedError("the fused kernel never materialises attention weights; "
-                                      "need_head_weights / before_softmax / attn_mask are unsupported")
+            raise NotImplementedError("per-head weights / raw scores / attn_mask are never used by mDT and unsupported here")
         tgt_len, bsz, embed_dim = query.size()
         assert embed_dim == self.embed_dim, f"query dim {embed_dim} != {self.embed_dim}"
         if key_padding_mask is not None and key_padding_mask.dim() == 0:
@@ -96,16 +95,23 @@ class MultiheadAttention(QKVFusedMixin, nn.Module):
         if attn_bias is not None:
             inputs.append(attn_bias.reshape(bsz, self.num_heads, tgt_len, tgt_len).float().contiguous())
 
+        stash = {} if need_weights else None
+
         def run(tape, xv, bv=None):
             spec = E.AttnSpec(nseq=bsz, S=tgt_len, H=self.num_heads, seq_stride=1, pos_stride=bsz, scale=self.scaling,
                               dense_bias=None if bv is None else bv.data, dense_bias_var=bv, key_pad=kpad)
-            return (self._fwd(tape, xv, spec),)
+            return (self._fwd(tape, xv, spec, stash=stash),)
 
         params = [p for p in self.parameters()]
         (out,) = E.run_tape(run, inputs, params)
-        # need_weights=True in the reference returns head-averaged probabilities; the encoder
-        # always passes need_weights=False, and so does this path
-        return out.view(tgt_len, bsz, embed_dim), None
+        weights = None
+        if need_weights:
+            # head-averaged softmax probabilities BEFORE dropout, [bsz, tgt_len, src_len] (:205-214, the reference's
+            # default); recomputed from q, k and the forward's log-sum-exp — the fused kernel never stores them.  Returned
+            # detached: nothing in mDT differentiates through them.
+            from .. import ops
+            weights = ops.attention_mean_probs(stash["qkv"], stash["lse"], bsz, tgt_len, self.num_heads, **stash["kw"])
+        return out.view(tgt_len, bsz, embed_dim), weights
 
     def apply_sparse_mask(self, attn_weights, tgt_len: int, src_len: int, bsz: int):
         return attn_weights

@@ -16,7 +16,7 @@ from ._lib import (EPI_ACCUM, EPI_ATOMIC, EPI_AUX_GRAD, EPI_BIAS, EPI_COLSUM, EP
 
 __all__ = [
     "bert_embed_rows",
-    "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "graph_attn_bias",
+    "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "attention_mean_probs", "graph_attn_bias",
     "row_axpby", "row_scatter_add", "bert_embed_sum", "vit_patchify", "vit_assemble", "graph_node_feature",
     "tanh_fwd", "tanh_bwd", "node_ce", "contrastive_loss", "fp8_quantize", "fp8_scale_update", "gemm_fp8", "cast", "transpose2d", "dropout", "dropout_mask",
     "EPI_BIAS", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_ACCUM", "EPI_ATOMIC", "EPI_DROPOUT", "EPI_AUX_GRAD", "EPI_MULAUX",
@@ -147,6 +147,18 @@ def attention_fwd(qkv, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None,
                    virt, key_pad, drop_p, drop_seed, seq_offsets, q_limit)
     check(lib.mdt_attention_fwd(stream(), C.byref(a)), "mdt_attention_fwd")
     return out, lse
+
+
+def attention_mean_probs(qkv, lse, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None, key_mask=None, dense_bias=None,
+                         attn_bias=None, spatial_pos=None, sp_table=None, virt=None, key_pad=None):
+    """Head-averaged attention probabilities f32[nseq, S, S] from the qkv buffer and the forward's lse."""
+    D = qkv.shape[1] // 3
+    hd = D // H
+    out = torch.empty(nseq, S, S, dtype=torch.float32, device=qkv.device)
+    a = _attn_args(qkv, qkv, lse, nseq, S, H, hd, S if seq_stride is None else seq_stride, pos_stride,
+                   hd ** -0.5 if scale is None else scale, key_mask, dense_bias, attn_bias, spatial_pos, sp_table, virt, key_pad)
+    check(lib.mdt_attention_mean_probs(stream(), C.byref(a), ptr(out)), "mdt_attention_mean_probs")
+    return out
 
 
 def attention_bwd(dout, qkv, out, lse, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None, key_mask=None,

@@ -534,3 +534,33 @@ def test_frozen_initial_encoders_stop_the_gradient_chain(monkeypatch):
     # hp "A": 2 + 2 pre-fusion blocks (5 backward GEMMs each with weight gradients skipped: 4 dgrads + ... ) and the two
     # embedding stages vanish from backward; what is left is the fusion / graph / head part
     assert counts["frozen/bwd"] < 0.7 * counts["live/bwd"], counts
+
+
+def test_multihead_attention_need_weights_matches_oracle():
+    """need_weights=True (the reference's default, modules/multihead_attention.py:205-214): head-averaged softmax
+    probabilities [B, T, T], recomputed by mdt_attention_mean_probs; checked against the oracle's attention."""
+    import math
+    from multimodaldiscussiontransformer_amd.modules import MultiheadAttention
+    T, B, D, H = 9, 3, 128, 8
+    mha = MultiheadAttention(D, H, dropout=0.0, self_attention=True).cuda()
+    with torch.no_grad():
+        for n, p in mha.named_parameters():
+            p.copy_(hw("mhaw/" + n, tuple(p.shape)))
+    x = hu("mhaw/x", (T, B, D)).cuda()
+    bias = hu("mhaw/b", (B, H, T, T), 2.0)
+    bias[1, :, :, 7:] = float("-inf")
+    kpm = torch.zeros(B, T, dtype=torch.bool)
+    kpm[2, 5:] = True
+    out, w = mha(x, x, x, bias.cuda(), key_padding_mask=kpm.cuda())          # need_weights defaults to True
+    out2, none = mha(x, x, x, bias.cuda(), key_padding_mask=kpm.cuda(), need_weights=False)
+    assert none is None and torch.equal(out, out2) and tuple(w.shape) == (B, T, T)
+    hd = D // H
+    wq, bq = mha.qkv_weight.detach().cpu(), mha.qkv_bias.detach().cpu()
+    q, k, v = (torch.nn.functional.linear(x.cpu(), wq[i * D:(i + 1) * D], bq[i * D:(i + 1) * D]) for i in range(3))
+    q = (q * hd ** -0.5).view(T, B * H, hd).transpose(0, 1)
+    k = k.view(T, B * H, hd).transpose(0, 1)
+    s_ = torch.bmm(q, k.transpose(1, 2)).view(B, H, T, T) + bias
+    s_ = s_.masked_fill(kpm[:, None, None, :], float("-inf"))
+    ref = torch.softmax(s_, dim=-1).mean(dim=1)
+    torch.testing.assert_close(w.cpu(), ref, atol=1e-5, rtol=1e-4)
+    torch.testing.assert_close(w.sum(-1).cpu(), torch.ones(B, T), atol=1e-5, rtol=1e-5)
