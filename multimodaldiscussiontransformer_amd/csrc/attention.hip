@@ -593,6 +593,7 @@ template <bool BWD>
 static int dispatch(hipStream_t st, const AttnParams& p) {
   const mdt_attn_fwd_args& a = p.f;
   const bool st_bias = a.attn_bias != nullptr;
+  if (a.S > 272) return attention_long_dispatch(st, p, BWD);      // discussion trees with more than 271 comments
   if (a.dtype == MDT_BF16) {
     // a plain dense bias (no structural terms) is only handled by the kernels in this file
     const bool dense_only = (a.dense_bias != nullptr || p.d_dense_bias != nullptr) && !st_bias;

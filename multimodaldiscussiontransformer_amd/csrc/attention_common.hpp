@@ -68,5 +68,6 @@ __device__ __forceinline__ float attn_drop_scale(const DropCfg& d, int bh, int S
 
 int attention_v2_dispatch(hipStream_t st, const AttnParams& p, bool bwd);
 int attention_v3_bwd_dispatch(hipStream_t st, const AttnParams& p);
+int attention_long_dispatch(hipStream_t st, const AttnParams& p, bool bwd);     // S > 272: attention_long.hip
 
 }  // namespace mdt

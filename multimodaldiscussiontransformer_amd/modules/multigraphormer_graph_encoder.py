@@ -332,19 +332,17 @@ class MultiGraphormerGraphEncoder(nn.Module):
             tape.record(lambda: tape.on_params_ready(image_side))
         return text, glob, rows
 
-    MAX_ATTENTION_TOKENS = 272      # one workgroup holds a whole (sequence, head) in LDS / registers (csrc/attention*.hip)
+    MAX_ATTENTION_TOKENS = 272      # one workgroup holds a whole (sequence, head) on chip (csrc/attention*.hip)
 
     def check_sequence_limits(self, pb: PackedBatch):
-        """The attention kernels are single-pass over at most 272 tokens: 271 comments per discussion tree (+ the graph
-        token), nb + L text tokens, nb + P image tokens.  The reference has no such limit (--max-nodes 10000 is declared
-        and never enforced, tasks/task.py:41-44); a batch beyond it is refused HERE, with the numbers, instead of failing
-        inside forward after half the step was enqueued."""
+        """Text (nb + L tokens) and image (nb + P tokens) sequences run on the single-pass attention kernels, at most 272
+        tokens: a batch beyond that is refused HERE, with the numbers, instead of failing inside forward after half the
+        step was enqueued.  Discussion TREES may be of any size, as in the reference (--max-nodes 10000 is declared and
+        never enforced, tasks/task.py:41-44): graph attention over more than 271 comments takes the key-chunked kernels
+        of csrc/attention_long.hip (same numbers, plain fp32 FMAs instead of MFMA)."""
         lim = self.MAX_ATTENTION_TOKENS
         nb = self.num_bottle_neck
         npatch = (self.vit_config["image_size"] // self.vit_config["patch"]) ** 2 + 1
-        if pb.T > lim:
-            raise ValueError(f"a discussion tree of this batch has {pb.N} comments: graph attention handles at most {lim - 1} "
-                             f"per tree (set --max-nodes {lim - 1} / prune the tree as Pre-Processing/3-prune-trees.py does)")
         if nb + pb.L > lim:
             raise ValueError(f"{nb} bottleneck + {pb.L} text tokens per comment exceed the {lim}-token attention limit")
         if pb.I > 0 and nb + npatch > lim:

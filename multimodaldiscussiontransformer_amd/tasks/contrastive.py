@@ -18,4 +18,4 @@ class ContrastiveLearningTask(Task):
 
     def get_batched_dataset(self, dataset):
         from ..data.dataset import ContrastiveBatchedDataDataset
-        return ContrastiveBatchedDataDataset(dataset, spatial_pos_max=self.cfg.spatial_pos_max, device=self.collate_device, sample_filter=self.filter_oversized)
+        return ContrastiveBatchedDataDataset(dataset, spatial_pos_max=self.cfg.spatial_pos_max, device=self.collate_device)

@@ -18,7 +18,7 @@ class NodePredictionTask(Task):
 
     def get_batched_dataset(self, dataset):
         from ..data.dataset import NodeBatchedDataDataset
-        return NodeBatchedDataDataset(dataset, spatial_pos_max=self.cfg.spatial_pos_max, device=self.collate_device, sample_filter=self.filter_oversized)
+        return NodeBatchedDataDataset(dataset, spatial_pos_max=self.cfg.spatial_pos_max, device=self.collate_device)
 
     def build_model(self, args):
         model = super().build_model(args)

@@ -78,16 +78,6 @@ class Task(FairseqTask):
         assert cfg.num_classes > 0, "Must set task.num_classes"
         return cls(cfg)
 
-    def filter_oversized(self, samples):
-        """Trees the attention kernels cannot take (more than 271 comments) are dropped with a warning; the reference
-        would run them (dense O(N^2) attention) — see MultiGraphormerGraphEncoder.check_sequence_limits."""
-        from ..modules import MultiGraphormerGraphEncoder
-        lim = min(MultiGraphormerGraphEncoder.MAX_ATTENTION_TOKENS - 1, int(self.cfg.max_nodes))
-        keep = [s for s in samples if s is None or len(s["parent"]) <= lim]
-        if len(keep) != len(samples):
-            logger.warning("dropped %d discussion tree(s) with more than %d comments", len(samples) - len(keep), lim)
-        return keep
-
     def load_dataset(self, split, **kwargs):
         """Load a dataset split (task.py:168-204): the envelope FairSeq's trainer iterates."""
         from ..data.dataset import EpochShuffleDataset, SampleEnvelopeDataset

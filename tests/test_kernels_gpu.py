@@ -599,3 +599,70 @@ def test_abi_rejects_bad_arguments_loudly(ops):
     # the library stays usable after errors
     out = ops.gemm(a, b)
     torch.testing.assert_close(out.float(), a.float() @ b.float().t(), atol=0.1, rtol=2e-2)
+
+
+# ----------------------------------------------------------------------------- long sequences (trees of > 271 comments)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("S,struct,p", [(300, True, 0.0), (273, True, 0.25), (700, False, 0.2)])
+def test_attention_beyond_272_tokens_key_chunked_path(ops, dtype, S, struct, p):
+    """csrc/attention_long.hip: graph attention over more comments than the single-pass kernels hold.  Against torch fp32
+    on the same inputs and the same dropout masks: output, log-sum-exp, dQ / dK / dV and the structural-bias gradients."""
+    import math
+    nseq, H, hd, seed = 2, 3, 64, 77
+    D = H * hd
+    g = torch.Generator().manual_seed(S)
+    qkv = (torch.randn(nseq * S, 3 * D, generator=g) * 0.5).to(dtype)
+    dout = torch.randn(nseq * S, D, generator=g).to(dtype)
+    kpad = torch.zeros(nseq, S, dtype=torch.uint8)
+    kpad[1, S - 40:] = 1
+    kw = {}
+    bias_ref = torch.zeros(nseq, H, S, S)
+    table = virt = None
+    if struct:
+        ab = torch.zeros(nseq, S, S)
+        far = torch.rand(nseq, S, S, generator=g) < 0.3
+        far[:, 0, :] = False
+        far[:, :, 0] = False
+        far = far | far.transpose(1, 2)
+        idx = torch.arange(S)
+        far[:, idx, idx] = False
+        ab[far] = float("-inf")
+        sp = torch.randint(1, 22, (nseq, S - 1, S - 1), generator=g, dtype=torch.int32)
+        table = (torch.randn(32, H, generator=g) * 0.3).to(dtype)
+        virt = (torch.randn(H, generator=g) * 0.3).to(dtype)
+        kw = dict(attn_bias=dev(ab), spatial_pos=dev(sp), sp_table=dev(table), virt=dev(virt))
+        tb = table.float().requires_grad_(True)
+        vt = virt.float().requires_grad_(True)
+        b = 2 * ab[:, None].expand(nseq, H, S, S).clone()
+        b[:, :, 1:, 1:] = b[:, :, 1:, 1:] + tb[sp.long()].permute(0, 3, 1, 2)
+        b[:, :, 1:, 0] = b[:, :, 1:, 0] + vt.view(1, H, 1)
+        b[:, :, 0, :] = b[:, :, 0, :] + vt.view(1, H, 1)
+        bias_ref = b
+    S2 = S + (S & 1)
+    mk = torch.ones(nseq, H, S, S)
+    if p > 0:
+        mk = ops.dropout_mask(nseq * H * S * S2, p, seed).view(nseq, H, S, S2)[..., :S].float().cpu() / (1 - p)
+    qr = qkv.float().view(nseq, S, 3 * D).requires_grad_(True)
+    q, k, v = qr.split(D, dim=-1)
+    hv = lambda t: t.reshape(nseq, S, H, hd).transpose(1, 2)
+    sc = hv(q) @ hv(k).transpose(-1, -2) * hd ** -0.5 + bias_ref
+    sc = sc.masked_fill(kpad.bool()[:, None, None, :], -math.inf)
+    oref = ((torch.softmax(sc, -1) * mk) @ hv(v)).transpose(1, 2).reshape(nseq * S, D)
+    lse_ref = torch.logsumexp(sc, -1)
+    oref.backward(dout.float())
+    out, lse = ops.attention_fwd(dev(qkv), nseq, S, H, key_pad=dev(kpad), drop_p=p, drop_seed=seed, **kw)
+    tol = dict(atol=2e-4, rtol=2e-4) if dtype == torch.float32 else dict(atol=4e-2, rtol=4e-2)
+    torch.testing.assert_close(out.float().cpu(), oref.detach(), **tol)
+    torch.testing.assert_close(lse.cpu(), lse_ref.detach(), atol=2e-3 if dtype == torch.float32 else 3e-2, rtol=1e-3)
+    extra = {}
+    if struct:
+        extra = dict(d_sp_table=torch.zeros(32, H, device="cuda"), d_virt=torch.zeros(H, device="cuda"))
+    dqkv, _ = ops.attention_bwd(dev(dout), dev(qkv), out, lse, nseq, S, H, key_pad=dev(kpad), drop_p=p, drop_seed=seed, **kw, **extra)
+    gt = dict(atol=1e-3, rtol=1e-3) if dtype == torch.float32 else dict(atol=0.12, rtol=6e-2)
+    torch.testing.assert_close(dqkv.float().cpu().view(nseq, S, 3 * D), qr.grad, **gt)
+    if struct:
+        st = dict(atol=2e-3, rtol=2e-3) if dtype == torch.float32 else dict(atol=0.3, rtol=0.1)
+        want = tb.grad.clone()
+        want[0] = 0                                   # padding_idx row never receives a gradient
+        torch.testing.assert_close(extra["d_sp_table"].cpu(), want, **st)
+        torch.testing.assert_close(extra["d_virt"].cpu(), vt.grad, **st)

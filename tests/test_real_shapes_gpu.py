@@ -177,3 +177,49 @@ def test_bf16_real_shapes_vs_fp32_oracle(kind):
           + "; ".join(f"{n} {r:.3e} (|g| {rn:.2e}, {ne} el)" for r, n, rn, ne in rows[:6]))
     bad = [(n, r) for r, n, _, _ in rows if r > BF16_GRAD_REL_L2]
     assert not bad, bad[:10]
+
+
+def test_tree_with_more_than_271_comments_fp32_vs_oracle():
+    """The reference takes any tree size (dense attention); here a 300-comment thread rides the key-chunked graph-attention
+    kernels (csrc/attention_long.hip) inside the full model: logits and every parameter gradient against the oracle."""
+    from multimodaldiscussiontransformer_amd import synthetic
+    from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
+    from multimodaldiscussiontransformer_amd.data.packer import pack_batch
+    from multimodaldiscussiontransformer_amd.models import GraphormerModel
+    from oracle import cases
+    hp = cases.tiny_hparams("A")
+    rng = np.random.Generator(np.random.PCG64(300))
+    trees = [synthetic.make_tree(300, rng, seq_len=8, vocab_size=hp.vocab_size, image_frac=0.01, image_size=hp.image_size, shape="deep", min_len=2),
+             synthetic.make_tree(5, rng, seq_len=8, vocab_size=hp.vocab_size, image_frac=0.0, image_size=hp.image_size, min_len=2)]
+    for i, t in enumerate(trees):
+        n = len(t["parent"])
+        t["y_mask"][:] = False
+        lab = list(range(0, n, 7))
+        t["y_mask"][lab] = True
+        t["y"] = np.asarray([(k + i) % 2 for k in range(len(lab))], dtype=np.float32)
+    model = GraphormerModel.build_model(model_args(hp), task=None)
+    fill_hash_weights(model)
+    model = model.cuda().train()
+    pb = pack_batch(trees, 5)
+    assert pb.T == 301
+    crit = GraphPredictionNodeCrossEntropy(None, positive_weight=1.5, negative_weight=1.0)
+    loss, n_lab, log = crit(model, {"nsamples": 2, "net_input": {"batched_data": pb.batched_data}})
+    loss.backward()
+    with torch.no_grad():
+        logits, glob = model(pb.batched_data)
+    W = R.make_weights(hp)
+    batch = R.to_torch_batch(S.collate(trees, 5))
+    lo, go = R.model_forward(W, hp, batch)
+    ol, counters = R.node_cross_entropy(lo, batch["y"], batch["y_mask"], hp)
+    ol.backward()
+    assert float((logits.cpu() - lo.detach()).abs().max()) < 1e-3
+    assert float((glob.cpu() - go.detach()).abs().max()) < 1e-3
+    for k in ("ncorrect", "num_positive_correct", "total_positive", "num_pred_positive"):
+        assert int(log[k]) == counters[k], k
+    grads = {k: p.grad for k, p in named_canonical_params(model).items()}
+    for name, w in W.items():
+        if w.grad is None:
+            continue
+        gr = split_qkv_grad(name, grads)
+        assert gr is not None, name
+        assert float((gr.float().cpu() - w.grad).abs().max()) <= 1e-3 * max(1.0, float(w.grad.abs().max())), name
