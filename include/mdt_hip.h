@@ -3,10 +3,13 @@
  *
  * Every entry point is `extern "C"`, takes plain pointers / sizes / a HIP stream
  * (as `void*` = hipStream_t) and NO torch types.  The caller owns every buffer,
- * workspace included; the library allocates nothing, keeps no global state besides
- * a thread-local error string, never synchronises the host and is re-entrant, so
- * forward and backward may run on different host threads and any call sequence can
- * be captured in a hipGraph.
+ * workspace included; the library allocates nothing and never synchronises the host.
+ * Its only state: a thread-local error string, the MDT_* environment switches read
+ * once at the first launch (mdt_reload_env re-reads them) and the pointer to the
+ * caller's tile-queue buffer (mdt_gemm_set_tile_queue, optional).  Entry points are
+ * re-entrant, so forward and backward may run on different host threads and any call
+ * sequence can be captured in a hipGraph.  (The profiling switch MDT_GEMM_STAMP=1 is
+ * the one exception: it allocates, synchronises and prints — never set in production.)
  *
  * Return value: 0 on success, a negative mdt_status otherwise; the message is
  * available through mdt_last_error_string() on the calling thread.
@@ -73,6 +76,15 @@ int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int trans_b,
              void* C, int64_t ldc, int epilogue, float alpha,
              const void* bias, const void* residual, int64_t ldr,
              void* aux, int64_t ldaux, int split_k, float drop_p, uint64_t drop_seed, float* colsum);
+/* Dynamic tile queue of the persistent GEMM (MDT_GEMM_DYNAMIC=1, for nodes where RCCL kernels hold compute units during
+ * backward): the queue heads live in a CALLER-OWNED device buffer of mdt_gemm_tile_queue_bytes() bytes, zero-initialised
+ * by the caller and registered once (NULL unregisters); the library allocates nothing.  Without it the static tile walk
+ * is used. */
+size_t mdt_gemm_tile_queue_bytes(void);
+int mdt_gemm_set_tile_queue(void* zeroed_device_buffer, size_t bytes);
+/* Re-read the MDT_* environment switches (tuning / diagnostics).  They are read once, at the first launch; a host that
+ * changes them afterwards (tests, A/B tools) calls this. */
+void mdt_reload_env(void);
 
 /* Inverted dropout as a stand-alone op: y[m, n] = x[m, n] * keep(seed, m*D + n) / (1 - p).  The mask is
  * a pure function of (seed, counter), so calling it on the gradient with the same seed is the backward

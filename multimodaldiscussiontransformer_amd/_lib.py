@@ -44,6 +44,9 @@ _SIGS = {
     "mdt_last_error_string": ([], C.c_char_p),
     "mdt_gemm": ([_vp, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _f, _vp, _vp, _i64,
                   _vp, _i64, _i, _f, C.c_uint64, _vp], _i),
+    "mdt_gemm_tile_queue_bytes": ([], C.c_size_t),
+    "mdt_gemm_set_tile_queue": ([_vp, C.c_size_t], _i),
+    "mdt_reload_env": ([], None),
     "mdt_dropout": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _i64, _f, C.c_uint64], _i),
     "mdt_dropout_mask": ([_vp, _i64, _f, C.c_uint64, _vp], _i),
     "mdt_colsum": ([_vp, _i, _i64, _i64, _vp, _i64, _vp, _vp], _i),
@@ -102,6 +105,23 @@ def _load():
 
 
 lib = _load()
+
+
+def reload_env():
+    """The library reads its MDT_* environment switches once; call this after changing them (tests, A/B tools)."""
+    lib.mdt_reload_env()
+
+
+_TILE_QUEUE = None
+
+
+def enable_dynamic_tile_queue(device="cuda"):
+    """Hand the persistent GEMM a zeroed device buffer for its dynamic tile queue (used when MDT_GEMM_DYNAMIC=1)."""
+    global _TILE_QUEUE
+    if _TILE_QUEUE is None:
+        _TILE_QUEUE = torch.zeros(lib.mdt_gemm_tile_queue_bytes() // 4, dtype=torch.int32, device=device)
+        check(lib.mdt_gemm_set_tile_queue(_TILE_QUEUE.data_ptr(), _TILE_QUEUE.numel() * 4), "mdt_gemm_set_tile_queue")
+    return _TILE_QUEUE
 
 
 def check(status: int, what: str = ""):

@@ -597,11 +597,11 @@ static int dispatch(hipStream_t st, const AttnParams& p) {
   if (a.dtype == MDT_BF16) {
     // a plain dense bias (no structural terms) is only handled by the kernels in this file
     const bool dense_only = (a.dense_bias != nullptr || p.d_dense_bias != nullptr) && !st_bias;
-    if (a.hd == 64 && !dense_only && getenv("MDT_ATTN_V1") == nullptr) {
+    if (a.hd == 64 && !dense_only && !switches().attn_v1) {
       if (!BWD) return attention_v2_dispatch(st, p, false);              // forward: register-resident P
       // backward, measured at C2 shapes (profiles/round1_attention_v2.txt): S <= 112 -> whole-row v2,
       // longer sequences -> chunked v3; tiny graphs (S <= 80) stay on the LDS-scratch kernel below
-      const char* force = getenv("MDT_ATTN_BWD");      // "v1" | "v2" | "v3" for A/B runs
+      const char* force = switches().attn_bwd[0] ? switches().attn_bwd : nullptr;      // MDT_ATTN_BWD = "v1" | "v2" | "v3" for A/B runs
       const bool drop = a.drop_p > 0.f;                // with dropout the whole-row v2 falls to 1 wave / SIMD: chunked v3 wins
       if (BWD && a.S > 256 && !force) return attention_v3_bwd_dispatch(st, p);   // ViT-L/14: 4 + 257 tokens
       const bool v1 = force ? !strcmp(force, "v1") : a.S <= 80;

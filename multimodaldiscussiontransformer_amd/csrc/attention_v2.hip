@@ -717,13 +717,13 @@ static int launch_v3(hipStream_t st, const AttnParams& p) {
     }
   }
   if constexpr (!STRUCT) {
-    if (s_pad <= 128 && getenv("MDT_ATTN_NO_OCC4") == nullptr) {
+    if (s_pad <= 128 && !switches().attn_no_occ4) {
       hipLaunchKernelGGL((attn_bwd_v3_occ4_kernel<64, DROP>), dim3(p.f.H, p.f.nseq), 256, lds, st, p, s_pad);
       return check_launch("attention_bwd_v3_occ4");
     }
     // long sequences (ViT: 13 tiles): LDS allows two workgroups per CU; 8 waves each in the 128-register build
     // = 4 waves per SIMD instead of 2
-    if (s_pad > 128 && getenv("MDT_ATTN_NO_W8") == nullptr) {      // in-call A/B at the ViT shape: +0.7 % on the step
+    if (s_pad > 128 && !switches().attn_no_w8) {      // in-call A/B at the ViT shape: +0.7 % on the step
       hipLaunchKernelGGL((attn_bwd_v3_occ4_kernel<64, DROP>), dim3(p.f.H, p.f.nseq), 512, lds, st, p, s_pad);
       return check_launch("attention_bwd_v3_w8");
     }

@@ -36,6 +36,25 @@ void set_error(const char* fmt, ...);
   } while (0)
 int check_launch(const char* what);
 
+// Environment switches (tuning / diagnostics; production runs set none of them).  Read ONCE, at the first launch that
+// asks — the hot path makes no getenv calls — and again only when the host calls mdt_reload_env() (tests, A/B tools).
+struct Switches {
+  int gemm_pp_dist;          // MDT_GEMM_PP_DIST   (default 4)
+  bool gemm_persist;         // MDT_GEMM_PERSIST   (default 1)
+  bool gemm_dynamic;         // MDT_GEMM_DYNAMIC   (default 0): dynamic tile queue, needs mdt_gemm_set_tile_queue
+  int gemm_group;            // MDT_GEMM_GROUP     (-1: unset)
+  bool gemm_stamp;           // MDT_GEMM_STAMP
+  bool gemm_no_spec;         // MDT_GEMM_NO_SPEC
+  int gemm_diag;             // MDT_GEMM_DIAG      (0: none)
+  char gemm_tile[16];        // MDT_GEMM_TILE      ("" unset)
+  bool gemm_no_pp;           // MDT_GEMM_NO_PP
+  bool attn_v1;              // MDT_ATTN_V1
+  char attn_bwd[8];          // MDT_ATTN_BWD       ("" unset)
+  bool attn_no_occ4;         // MDT_ATTN_NO_OCC4
+  bool attn_no_w8;           // MDT_ATTN_NO_W8
+};
+const Switches& switches();
+
 // ---------------------------------------------------------------- scalar conversions
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }

@@ -1295,13 +1295,17 @@ static int num_cus() {
   return n;
 }
 
+// dynamic tile queue: caller-owned device memory (mdt_gemm_set_tile_queue), 16 ints per set
+static int* g_tile_queues = nullptr;
+static int g_tile_queue_sets = 0;
+
 template <typename TOut>
 static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) {
   GemmParams p = p_in;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)p.split_k);
-  static const int dist = getenv("MDT_GEMM_PP_DIST") ? atoi(getenv("MDT_GEMM_PP_DIST")) : 4;
-  const char* pe = getenv("MDT_GEMM_PERSIST");     // read per call: tests toggle it
-  const bool persist_ok = pe == nullptr || atoi(pe) != 0;
+  const Switches& sw = switches();
+  const int dist = sw.gemm_pp_dist;
+  const bool persist_ok = sw.gemm_persist;
   const int nhs_total = 2 * (int)((p.K + T_BK - 1) / T_BK);
   const bool persist = persist_ok && sizeof(TOut) == 2 && p.split_k == 1 && nhs_total >= 4 && (int)grid.x > num_cus();
   if (persist) grid.x = (unsigned)num_cus();
@@ -1309,21 +1313,13 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   if (persist) {
     // MDT_GEMM_DYNAMIC=1: dynamic tile queue instead of the static round-robin walk (in-call A/B on an otherwise idle
     // chip: static is 1.5 % faster — two more barriers per tile, and raided tiles leave their XCD's L2; the queue is
-    // there for a node where other kernels — RCCL — hold compute units for long, see ddp.py).  512 queue sets are used in turn, each zeroed once
-    // here and put back to zero by the last workgroup of the launch that used it (launches of the two branch streams
-    // run concurrently, at most a few dozen launches apart in issue order).
-    static int* queues = nullptr;
+    // there for a node where other kernels — RCCL — hold compute units for long, see ddp.py).  The queue sets live in a
+    // CALLER-OWNED, zero-initialised device buffer (mdt_gemm_set_tile_queue; the library allocates nothing): they are
+    // used in turn, each put back to zero by the last workgroup of the launch that used it (launches of the two branch
+    // streams run concurrently, at most a few dozen launches apart in issue order).  Without a registered buffer the
+    // static walk is used.
     static unsigned turn = 0;
-    const char* de = getenv("MDT_GEMM_DYNAMIC");
-    if (de != nullptr && atoi(de) != 0) {
-      if (!queues) {
-        if (hipMalloc(&queues, 512 * 16 * sizeof(int)) != hipSuccess || hipMemset(queues, 0, 512 * 16 * sizeof(int)) != hipSuccess) {
-          (void)hipGetLastError();
-          queues = nullptr;
-        }
-      }
-      if (queues) p.tile_queue = queues + 16 * (turn++ & 511);
-    }
+    if (sw.gemm_dynamic && g_tile_queues) p.tile_queue = g_tile_queues + 16 * (turn++ % (unsigned)g_tile_queue_sets);
   }
   {
     // Tile order.  Row-major (group_n = tiles_n) unless B is too wide for an XCD's 4-MiB L2 and splits evenly in
@@ -1343,8 +1339,8 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
       // (more panels) be the slow index: column-major when dW is wider than tall (fc2: 1.66 -> 1.25 x operand bytes)
       if (p.split_k > 1 && p.tiles_n > p.tiles_m) p.group_n = 1;
     }
-    if (const char* g = getenv("MDT_GEMM_GROUP")) {
-      int v = atoi(g);
+    if (sw.gemm_group >= 0) {
+      int v = sw.gemm_group;
       if (v == 0) {
         const double a_bytes = (double)p.M * (double)p.k_chunk * 2.0, b_bytes = (double)p.N * (double)p.k_chunk * 2.0;
         const double rounds = (double)p.tiles_m * p.tiles_n / 256.0;
@@ -1359,7 +1355,7 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
       if (v >= 1) p.group_n = v < p.tiles_n ? v : p.tiles_n;
     }
   }
-  static const bool stamp = getenv("MDT_GEMM_STAMP") != nullptr;
+  const bool stamp = sw.gemm_stamp;
   const size_t nwg = (size_t)grid.x * grid.z;
   if (stamp) {
     if (hipMalloc(&p.stamps, nwg * 32) != hipSuccess) { (void)hipGetLastError(); p.stamps = nullptr; }
@@ -1388,8 +1384,7 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
     constexpr int E_BIAS = MDT_EPI_BIAS, E_DENSE = MDT_EPI_BIAS | MDT_EPI_RESIDUAL | MDT_EPI_DROPOUT,
                   E_FC1 = MDT_EPI_BIAS | MDT_EPI_GELU | MDT_EPI_AUX_GRAD /* HF blocks have no activation dropout */, E_RES = MDT_EPI_RESIDUAL,
                   E_DFC2 = MDT_EPI_MULAUX | MDT_EPI_COLSUM;
-    static const bool no_spec = getenv("MDT_GEMM_NO_SPEC") != nullptr;
-    const int e = no_spec ? -2 : p.epilogue;
+    const int e = sw.gemm_no_spec ? -2 : p.epilogue;
     if (!ta && !tb) {
       if (e == E_BIAS) LPS(false, false, E_BIAS)
       else if (e == E_DENSE) LPS(false, false, E_DENSE)
@@ -1530,7 +1525,7 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   p.tile_queue = nullptr;
   p.alpha_dev = p.alpha_dev2 = nullptr;
   p.group_n = 1 << 30;   // row-major unless launch_pp256 decides otherwise
-  if (const char* dg = getenv("MDT_GEMM_DIAG")) p.epilogue |= atoi(dg) << 20;   // 1: skip stores, 2: sc1 stores (direct epilogue only)
+  p.epilogue |= switches().gemm_diag << 20;   // diagnostics: 1 skip stores, 2 sc1 stores, 4 skewed starts, 8 every tile loads tile (0,0)'s panels
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_COLSUM) || (colsum && split_k == 1), "mdt_gemm: MDT_EPI_COLSUM needs a colsum buffer and split_k == 1");
   // tile128 contract: bf16, output dims that are tiled along a contiguous axis must be
   // whole tiles, 16-B aligned rows.
@@ -1559,7 +1554,7 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   }
   if (fast) {
     // big problems: 256-row tiles, one 8-wave block per CU; small ones keep 128x128 (2 blocks / CU)
-    const char* force = getenv("MDT_GEMM_TILE");      // "128" | "256x128" | "256x256" (tuning / A-B runs)
+    const char* force = switches().gemm_tile[0] ? switches().gemm_tile : nullptr;      // "128" | "256x128" | "256x256" | "pp" (tuning / A-B runs)
     const bool m256 = trans_a ? (M % 256 == 0) : true;
     const int64_t t256 = ((M + 255) / 256) * (N / 128) * p.split_k;
     const bool n256 = N % 256 == 0;
@@ -1574,7 +1569,7 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
     if (use256x256 || (force && m256 && n256 && !strcmp(force, "pp"))) {
       p.tiles_m = (int)((M + 255) / 256);
       p.tiles_n = (int)(N / 256);
-      const bool pp = force ? !strcmp(force, "pp") : (getenv("MDT_GEMM_NO_PP") == nullptr);
+      const bool pp = force ? !strcmp(force, "pp") : !switches().gemm_no_pp;
       if (pp) return out_dtype == MDT_F32 ? launch_pp256<float>(st, p, trans_a, trans_b)
                                           : launch_pp256<bf16_t>(st, p, trans_a, trans_b);
       return out_dtype == MDT_F32 ? launch_tile256<float, 256, 2, 4, 2>(st, p, trans_a, trans_b)
@@ -1595,6 +1590,16 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   if (dtype == MDT_F32) return launch_generic<float, float>(st, p, trans_a, trans_b);
   return out_dtype == MDT_F32 ? launch_generic<bf16_t, float>(st, p, trans_a, trans_b)
                               : launch_generic<bf16_t, bf16_t>(st, p, trans_a, trans_b);
+}
+
+extern "C" size_t mdt_gemm_tile_queue_bytes(void) { return (size_t)512 * 16 * sizeof(int); }
+
+extern "C" int mdt_gemm_set_tile_queue(void* zeroed_device_buffer, size_t bytes) {
+  if (zeroed_device_buffer == nullptr) { g_tile_queues = nullptr; g_tile_queue_sets = 0; return MDT_OK; }
+  MDT_CHECK_ARG(bytes >= 16 * sizeof(int) && ((uintptr_t)zeroed_device_buffer & 3) == 0, "mdt_gemm_set_tile_queue: buffer too small / unaligned");
+  g_tile_queues = (int*)zeroed_device_buffer;
+  g_tile_queue_sets = (int)(bytes / (16 * sizeof(int)));
+  return MDT_OK;
 }
 
 extern "C" int mdt_gemm_fp8(void* stream, int a_format, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,

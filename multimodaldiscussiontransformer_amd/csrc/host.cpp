@@ -1,6 +1,8 @@
 // Host-side pieces of the C ABI: error plumbing and the native packer (tree structure
 // tensors), compiled with hipcc as plain C++.
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <cmath>
@@ -29,8 +31,41 @@ int check_launch(const char* what) {
   return MDT_OK;
 }
 
+static Switches g_sw;
+static bool g_sw_valid = false;
+
+static void read_switches() {
+  auto flag = [](const char* n) { return getenv(n) != nullptr; };
+  auto num = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
+  auto str = [](const char* n, char* dst, size_t cap) {
+    const char* v = getenv(n);
+    dst[0] = 0;
+    if (v) { strncpy(dst, v, cap - 1); dst[cap - 1] = 0; }
+  };
+  g_sw.gemm_pp_dist = num("MDT_GEMM_PP_DIST", 4);
+  g_sw.gemm_persist = num("MDT_GEMM_PERSIST", 1) != 0;
+  g_sw.gemm_dynamic = num("MDT_GEMM_DYNAMIC", 0) != 0;
+  g_sw.gemm_group = num("MDT_GEMM_GROUP", -1);
+  g_sw.gemm_stamp = flag("MDT_GEMM_STAMP");
+  g_sw.gemm_no_spec = flag("MDT_GEMM_NO_SPEC");
+  g_sw.gemm_diag = num("MDT_GEMM_DIAG", 0);
+  str("MDT_GEMM_TILE", g_sw.gemm_tile, sizeof(g_sw.gemm_tile));
+  g_sw.gemm_no_pp = flag("MDT_GEMM_NO_PP");
+  g_sw.attn_v1 = flag("MDT_ATTN_V1");
+  str("MDT_ATTN_BWD", g_sw.attn_bwd, sizeof(g_sw.attn_bwd));
+  g_sw.attn_no_occ4 = flag("MDT_ATTN_NO_OCC4");
+  g_sw.attn_no_w8 = flag("MDT_ATTN_NO_W8");
+  g_sw_valid = true;
+}
+
+const Switches& switches() {
+  if (!g_sw_valid) read_switches();
+  return g_sw;
+}
+
 }  // namespace mdt
 
+extern "C" void mdt_reload_env(void) { mdt::read_switches(); }
 extern "C" int mdt_abi_version(void) { return MDT_ABI_VERSION; }
 extern "C" const char* mdt_last_error_string(void) { return mdt::g_err; }
 

@@ -235,6 +235,10 @@ class DataParallel:
         # step during which the ~13 bucket all-reduces are resident at all, and with two streams the other branch's
         # kernels fill a CU that waits.  The static walk therefore stays the default at every world size; the switch
         # is for a node where the collectives turn out to be slow.
+        import os as _os
+        if flat.is_cuda and _os.environ.get("MDT_GEMM_DYNAMIC", "0") not in ("", "0"):
+            from . import _lib
+            _lib.enable_dynamic_tile_queue(flat.device)       # the queue heads live in memory this process owns
         if flat.is_cuda and getattr(ge, "two_streams", False):
             from . import engine
             self.bucketer.compute_streams = [torch.cuda.current_stream(), engine.side_stream(flat.device)]

@@ -17,3 +17,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _library_sees_the_restored_environment():
+    """libmdt_hip reads its MDT_* switches once; a test that changed them (monkeypatch) tells the library, and after the
+    test — when monkeypatch has put the environment back — the library re-reads it."""
+    yield
+    try:
+        from multimodaldiscussiontransformer_amd import _lib
+        _lib.reload_env()
+    except Exception:  # noqa: BLE001  (library not built: CPU-only collection)
+        pass

@@ -115,6 +115,8 @@ def test_attention_dropout(ops, dtype, bwd, nseq, S, H, monkeypatch):
     hd, p, seed = 64, 0.3, 4242
     if bwd:
         monkeypatch.setenv("MDT_ATTN_BWD", bwd)   # every backward kernel family regenerates the forward's mask
+        from multimodaldiscussiontransformer_amd import _lib
+        _lib.reload_env()
     D = H * hd
     qkv = rnd(nseq, S, 3 * D, seed=7).to(dtype)
     dout = rnd(nseq, S, D, seed=8).to(dtype)

@@ -9,6 +9,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from multimodaldiscussiontransformer_amd import _lib as L
+
 pytestmark = pytest.mark.gpu
 
 
@@ -164,10 +166,14 @@ def test_gemm_bf16_out_big_tiles(ops, M, N, K, tb, monkeypatch):
     for persist, dynamic in (("1", "0"), ("1", "1"), ("0", "0")):     # static walk, dynamic tile queue, one tile per workgroup
         monkeypatch.setenv("MDT_GEMM_PERSIST", persist)
         monkeypatch.setenv("MDT_GEMM_DYNAMIC", dynamic)
+        L.enable_dynamic_tile_queue()                                 # caller-owned queue memory (the library allocates nothing)
+        L.reload_env()                                                # the switches are cached: say that they changed
         for _ in range(2):                                            # twice: the queue must come back zeroed
             out = ops.gemm(ad, bd, trans_b=bool(tb))
             torch.testing.assert_close(out.float(), ref, **tol)
     monkeypatch.setenv("MDT_GEMM_DYNAMIC", "0")
+    monkeypatch.setenv("MDT_GEMM_PERSIST", "1")
+    L.reload_env()
     cs = torch.zeros(N, dtype=torch.float32).cuda()
     out = ops.gemm(ad, bd, trans_b=bool(tb), bias=dev(bias), residual=dev(res), colsum=cs)
     full = ref + dev(bias).float() + dev(res).float()
@@ -519,6 +525,7 @@ def test_attention_ragged_sequences_equal_masked_padding(ops, dtype, bwd, Smax, 
         pytest.skip("whole-row backward covers S <= 112")
     if bwd:
         monkeypatch.setenv("MDT_ATTN_BWD", bwd)
+        L.reload_env()
     hd, p, seed = 64, 0.25, 31
     D = H * hd
     lens = [Smax, 1, 17, Smax - 3, 5, 33 if Smax > 33 else 2]

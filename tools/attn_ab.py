@@ -19,7 +19,9 @@ for (nseq, S, name) in [(2048, 104, "bert"), (512, 201, "vit")]:
         line = f"{name} p={p}: fwd {t*1e3:.3f} ms |"
         for v in ("v1", "v2", "v3"):
             os.environ["MDT_ATTN_BWD"] = v
+            __import__("multimodaldiscussiontransformer_amd._lib", fromlist=["x"]).reload_env()
             t = timeit(lambda: ops.attention_bwd(dout, qkv, out, lse, nseq, S, H, drop_p=p, drop_seed=5))
             line += f" bwd {v} {t*1e3:.3f} ms"
         os.environ.pop("MDT_ATTN_BWD")
+        __import__("multimodaldiscussiontransformer_amd._lib", fromlist=["x"]).reload_env()
         print(line, flush=True)

@@ -96,16 +96,22 @@ def rest(M, dev, bf):
             ex = dict(d_sp_table=torch.zeros(512, H, device=dev), d_virt=torch.zeros(H, device=dev))
         import os
         os.environ["MDT_ATTN_BWD"] = "v1"
+        __import__("multimodaldiscussiontransformer_amd._lib", fromlist=["x"]).reload_env()
         t = timeit(lambda: ops.attention_bwd(dout, qkv, out, lse, nseq, S, H, **kw, **ex))
         os.environ.pop("MDT_ATTN_BWD")
+        __import__("multimodaldiscussiontransformer_amd._lib", fromlist=["x"]).reload_env()
         print(f"{name:6s} bwd (v1): {t*1e3:8.3f} ms  {2.5*fl/t/1e12:7.1f} TF/s (algorithmic 10 S^2 d)")
         os.environ["MDT_ATTN_BWD"] = "v2"
+        __import__("multimodaldiscussiontransformer_amd._lib", fromlist=["x"]).reload_env()
         t = timeit(lambda: ops.attention_bwd(dout, qkv, out, lse, nseq, S, H, **kw, **ex))
         os.environ.pop("MDT_ATTN_BWD")
+        __import__("multimodaldiscussiontransformer_amd._lib", fromlist=["x"]).reload_env()
         print(f"{name:6s} bwd (v2): {t*1e3:8.3f} ms  {2.5*fl/t/1e12:7.1f} TF/s")
         os.environ["MDT_ATTN_BWD"] = "v3"
+        __import__("multimodaldiscussiontransformer_amd._lib", fromlist=["x"]).reload_env()
         t = timeit(lambda: ops.attention_bwd(dout, qkv, out, lse, nseq, S, H, **kw, **ex))
         os.environ.pop("MDT_ATTN_BWD")
+        __import__("multimodaldiscussiontransformer_amd._lib", fromlist=["x"]).reload_env()
         print(f"{name:6s} bwd (v3): {t*1e3:8.3f} ms  {2.5*fl/t/1e12:7.1f} TF/s")
     print("== layernorm bf16 ==")
     x = torch.randn(M, 768, device=dev, dtype=bf); g = torch.ones(768, device=dev, dtype=bf); bb = torch.zeros(768, device=dev, dtype=bf)
