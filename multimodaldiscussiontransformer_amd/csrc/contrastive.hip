@@ -12,7 +12,7 @@
 //   counters : pred_ij = round(sigmoid(sim_ij)); ``pred == targets`` broadcasts y along the last axis as well:
 //              ncorrect = #{pred_ij == y_j}, positive_correct = #{pred_ij == y_j == 1}, total_positive = #{y_j == 1}
 //              (over B, not B^2), pred_positive = #{pred_ij == 1}                                (:153-161)
-//   backward : G_ij = W_ij (sigmoid(sim_ij) - T_ij);  dn_i = scale * sum_j (G_ij + G_ji) n_j;
+//   backward : G_ij = W_ij (sigmoid(sim_ij) - T_ij)   (fp32);  dn_i = scale * sum_j (G_ij + G_ji) n_j;
 //              de_i = (dn_i - n_i <n_i, dn_i>) / ||e_i||
 //
 // B is the number of trees on this GPU (tens to a few hundred), D = 768 / 1024: a few MFLOP.  Three small launches —
@@ -74,14 +74,15 @@ __global__ __launch_bounds__(1024) void cl_pair_kernel(int B, int D, const float
     if (i == j) w = 0.f;
     // binary_cross_entropy_with_logits with the reference's HALF target matrix (.half(), :122): PyTorch evaluates
     // (1 - target).mul_(input).sub_(log_sigmoid(input)).mul_(weight) in place on the half tensor, i.e. every step
-    // rounds to half, the sum is taken in fp32 and stored as half; autograd hands back half(weight) * (sigmoid - t).
+    // rounds to half, the sum is taken in fp32 and stored as half; the op's own backward formula is
+    // (sigmoid(x) - t) * weight in fp32 (checked against torch CPU with weights that half cannot represent).
     const float ls = fminf(x, 0.f) - log1pf(expf(-fabsf(x)));           // log_sigmoid(x), fp32
     float e = round_f16((1.f - tf) * x);
     e = round_f16(e - ls);
     e = round_f16(e * w);
     if (w != 0.f) loss += e;
     const float sg = 1.0f / (1.0f + expf(-x));
-    G[p] = (w != 0.f) ? round_f16(w) * (sg - tf) : 0.f;
+    G[p] = (w != 0.f) ? w * (sg - tf) : 0.f;     // the backward formula applies the weight in fp32
     const float pred = rintf(sg);                           // round half to even, like torch.round
     const bool ok = pred == y[j];
     c_ok += ok;

@@ -397,7 +397,7 @@ def contrastive_loss(embeddings, y, hard_y, scale=20.0, soft_negative_weight=0.0
     sim = (torch.mm(nA, nA.transpose(0, 1)) * scale).float()
     targets = y.float()
     # .half() as in the reference (:122, :126): binary_cross_entropy_with_logits then runs its in-place chain on a
-    # HALF tensor (every step rounds to half, the loss value is a half) and autograd returns half(weight) * (sigmoid - t)
+    # HALF tensor (every step rounds to half, the loss value is a half); its backward formula works in fp32
     target_matrix = targets.unsqueeze(1).eq(targets).half()
     hard_matrix = hard_y.float().unsqueeze(1).eq(targets).half()
     soft_labels = torch.logical_and(target_matrix.eq(0), hard_matrix.eq(0))

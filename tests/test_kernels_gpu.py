@@ -593,8 +593,8 @@ def test_abi_rejects_bad_arguments_loudly(ops):
         ops.gemm(a, b, epilogue=ops.EPI_DROPOUT, drop_p=1.0)
     H, hd = 2, 64
     with pytest.raises(MdtError, match="272|exceeds|limit"):
-        S = 300
-        ops.attention_fwd(dev(rnd(S, 3 * H * hd, seed=3).to(bf)), 1, S, H)   # longer than one attention call supports
+        S = 300     # longer than the single-pass kernels hold: plain sequences take the key-chunked path, RAGGED ones are refused
+        ops.attention_fwd(dev(rnd(S, 3 * H * hd, seed=3).to(bf)), 1, S, H, seq_offsets=dev(torch.tensor([0, S], dtype=torch.int32)))
     S = 40
     qkv = dev(rnd(2 * S, 3 * H * hd, seed=4).to(bf))
     off = dev(torch.tensor([0, S, 2 * S], dtype=torch.int32))
