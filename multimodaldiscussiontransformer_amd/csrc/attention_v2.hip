@@ -702,6 +702,221 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   attn_bwd_v3_body<HD, false, DROP, false>(P, s_pad);   // the 128-register build has no room for the look-ahead
 }
 
+// ---------------------------------------------------------------------------- backward in ONE pass (v4)
+// The two-pass kernels above compute S, dP, the softmax and the dropout decisions twice — once with queries on the
+// lanes (dQ) and once with keys on the lanes (dK, dV) — because either gradient wants the 16 x 16 tiles of dS in the
+// orientation the other one does not have.  Here the keys-on-lanes pass is the ONLY pass: besides dV^T += dO^T P and
+// dK^T += Q^T dS it leaves every dS tile in LDS as bf16, TRANSPOSED ([key][query]: a lane holds four consecutive
+// queries of one key = one ds_write_b64 per tile), and a light second phase reads those tiles back with
+// ds_read_b64_tr_b16 as the B operand of dQ^T = K^T dS^T — the same row permutation as every other operand pair of
+// this file, so still nothing is shuffled between lanes.  Against v3: 40 instead of 56 MFMAs per 16 x 64 block, the
+// exp2 / mixer / select VALU stream once instead of twice, three operand stagings instead of four (V never enters
+// LDS: its fragments come straight from global memory).  The price is the dS image: S x S x 2 bytes of LDS on top
+// of two operand images (154 KiB at S = 201: one 16-wave workgroup per CU, the same 4 waves per SIMD as the 8-wave
+// pairs of v3), so the host takes this kernel where that fits and pays (launch_v3 below).
+//   phase 1 (keys on lanes, a wave owns key tiles, walks the queries in pairs of tiles):
+//            S = Q K^T, dP = dO V^T -> P, dS -> dV^T, dK^T (registers) and dS^T -> LDS
+//   phase 2 (queries on lanes, a wave owns query tiles): dQ^T = K^T dS^T with K staged where Q was
+__device__ __forceinline__ bf16x8 v2_frag_tr_ld(const bf16_t* img, int ld, int t0, int c0, int lane, bool second) {
+  const int g = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
+  const bf16_t* a = img + (t0 * 16 + 4 * g + q4) * ld + c0 + pp * 4;
+  const bf16x4 lo = lds_read_tr16(a);
+  bf16x4 hi = bf16x4{0, 0, 0, 0};
+  if (second) hi = lds_read_tr16(a + 16 * ld);
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int HD, bool DROP>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_v4_kernel(AttnParams P, int rows_img, int ldq) {
+  constexpr int ND = HD / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const mdt_attn_fwd_args& a = P.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = blockDim.x, nw = nthr >> 6;
+  const int h = blockIdx.x, seq = blockIdx.y;
+  const int SL = a.S, D = a.H * HD;
+  const int S = a.seq_offsets ? a.seq_offsets[seq + 1] - a.seq_offsets[seq] : a.S;
+  const int64_t row0 = a.seq_offsets ? (int64_t)a.seq_offsets[seq] : (int64_t)seq * a.seq_stride;
+  const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * a.ld_qkv + h * HD;
+  const bf16_t* dout = (const bf16_t*)P.dout + row0 * P.ld_dout + h * HD;
+  const bf16_t* outp = (const bf16_t*)a.out + row0 * a.ld_out + h * HD;
+  bf16_t* dqkv = (bf16_t*)P.dqkv + row0 * P.ld_dqkv + h * HD;
+  const int64_t tld = a.pos_stride * a.ld_qkv, dld = a.pos_stride * P.ld_dout, old_ = a.pos_stride * a.ld_out,
+                gld = a.pos_stride * P.ld_dqkv;
+  bf16_t* img0 = (bf16_t*)smem;                       // Q, then K
+  bf16_t* img1 = img0 + rows_img * V2_LD;              // dO
+  float* s_kb = (float*)(img1 + rows_img * V2_LD);
+  float* s_lse = s_kb + rows_img;
+  float* s_delta = s_lse + rows_img;
+  bf16_t* dsT = (bf16_t*)(s_delta + rows_img);         // [16 * tiles][ldq]: dS^T, key-major
+  BiasCtx bc{seq, h, S, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
+  const int n_t = (S + 15) >> 4;
+  const int rows_live = ((n_t + 1) >> 1) * 32;         // this sequence's rows, in pairs of tiles (zero rows past S)
+  v2_stage<HD>(img0, qkv, tld, S, rows_live, tid, nthr);    // Q
+  const float ik = DROP ? P.drop.inv_keep : 1.0f, rik = 1.0f / ik;
+  // dO is staged by the same (row, 16-byte chunk) walk that forms delta = rowsum(dO * O): the 8 lanes of a row hold
+  // its 8 chunks, three shuffles finish the row (rows_live * 8 is a multiple of 64: whole waves, no divergence)
+  {
+    const int q_rows = (a.q_limit > 0 && ((a.q_limit + 15) & ~15) < S) ? ((a.q_limit + 15) & ~15) : S;   // rows the forward computed
+    for (int e = tid; e < rows_live * (HD / 8); e += nthr) {
+      const int r = e / (HD / 8), c8 = e - r * (HD / 8);
+      bf16x8 gv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      float de = 0.f;
+      if (r < S) {
+        gv = *(const bf16x8*)(dout + r * dld + c8 * 8);
+        if (r < q_rows) {
+          const bf16x8 o = *(const bf16x8*)(outp + r * old_ + c8 * 8);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) de += (float)o[k] * (float)gv[k];
+        }
+      }
+      *(bf16x8*)(img1 + r * V2_LD + c8 * 8) = gv;
+      de += __shfl_xor(de, 1, 64);
+      de += __shfl_xor(de, 2, 64);
+      de += __shfl_xor(de, 4, 64);
+      if (c8 == 0) s_delta[r] = de * rik;
+    }
+    for (int i = tid; i < rows_live; i += nthr) {
+      s_kb[i] = key_only_bias<bf16_t>(bc, i);
+      const float l = i < q_rows ? a.lse[((int64_t)seq * a.H + h) * SL + i] : -INFINITY;
+      s_lse[i] = (l == -INFINITY) ? INFINITY : l * LOG2E;
+    }
+  }
+  __syncthreads();
+  const int drop_bh = seq * a.H + h;
+  const uint32_t s2h = (uint32_t)((SL + 1) >> 1);
+  const float scale2 = a.scale * LOG2E;
+  const int g = lane >> 4, c = lane & 15;
+  const int n_tq = (a.q_limit > 0 && ((a.q_limit + 15) >> 4) < n_t) ? (a.q_limit + 15) >> 4 : n_t;
+  const int n_pair_q = (n_tq + 1) >> 1, n_pair_k = (n_t + 1) >> 1;
+
+  // ------------------------------------------------------------------ phase 1 (keys on lanes)
+  const int odd = c & 1;
+  const uint32_t base_rp = (uint32_t)(drop_bh * SL) * s2h;
+  for (int kt = wave; kt < n_t; kt += nw) {
+    const int key0 = kt * 16;
+    const int key = key0 + c;
+    const bool kok = key < S;
+    const float kb = s_kb[key];
+    bf16x8 fk[HD / 32], fv[HD / 32];
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      fk[ks] = v2_frag_glb(qkv + D, tld, S, key0, ks * 32, lane);
+      fv[ks] = v2_frag_glb(qkv + 2 * D, tld, S, key0, ks * 32, lane);
+    }
+    const uint32_t kh = base_rp + (uint32_t)(key >> 1);
+    bf16_t* ds_row = dsT + (key0 + c) * ldq + 4 * g;
+    f32x4 dv[ND], dk[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) { dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int pr = 0; pr < n_pair_q; ++pr) {
+      const int t0 = 2 * pr;
+      f32x4 sc[2], dp[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { sc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) {
+          sc[t] = mfma_bf16(v2_frag_lds(img0, (t0 + t) * 16, ks * 32, lane), fk[ks], sc[t]);   // S[q][key]
+          dp[t] = mfma_bf16(v2_frag_lds(img1, (t0 + t) * 16, ks * 32, lane), fv[ks], dp[t]);   // dP[q][key]
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int qb = (t0 + t) * 16 + 4 * g;
+        const f32x4 l2v = *(const f32x4*)(s_lse + qb);
+        const f32x4 dlv = *(const f32x4*)(s_delta + qb);
+        bool keep[4] = {true, true, true, true};
+        if constexpr (DROP) {
+          const uint32_t ra = kh + (uint32_t)(qb + 2 * odd) * s2h;
+          const uint32_t wa = drop_mix(ra ^ P.drop.key), wb = drop_mix((ra + s2h) ^ P.drop.key);
+          const uint32_t pa = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wa, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+          const uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wb, 0xB1, 0xF, 0xF, false);
+          const uint32_t w[4] = {odd ? pa : wa, odd ? pb : wb, odd ? wa : pa, odd ? wb : pb};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) keep[r] = ((w[r] >> (16 * odd)) & 0xFFFFu) >= P.drop.thresh;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = __builtin_fmaf(sc[t][r], scale2, kb);
+          const float p = __builtin_amdgcn_exp2f(v - l2v[r]);
+          const float dpv = keep[r] ? dp[t][r] : 0.f;
+          sc[t][r] = keep[r] ? p : 0.f;
+          dp[t][r] = p * (dpv - dlv[r]);
+        }
+      }
+      const bf16x8 fp = v2_pack(sc[0], sc[1]);
+      const bf16x8 fs = v2_pack(dp[0], dp[1]);
+      // dS^T[key][q]: the lane's four queries of either tile are contiguous — one 8-byte write per tile
+      *(bf16x4*)(ds_row + t0 * 16) = bf16x4{fs[0], fs[1], fs[2], fs[3]};
+      if (t0 + 1 < n_tq) *(bf16x4*)(ds_row + t0 * 16 + 16) = bf16x4{fs[4], fs[5], fs[6], fs[7]};
+#pragma unroll
+      for (int d = 0; d < ND; ++d) {
+        dv[d] = mfma_bf16(v2_frag_tr(img1, t0, d * 16, lane), fp, dv[d]);
+        dk[d] = mfma_bf16(v2_frag_tr(img0, t0, d * 16, lane), fs, dk[d]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kok) {
+      const float os = a.scale * ik;
+      bf16_t* krow = dqkv + (int64_t)key * gld + D + 4 * g;
+      bf16_t* vrow = dqkv + (int64_t)key * gld + 2 * D + 4 * g;
+#pragma unroll
+      for (int d = 0; d < ND; ++d) {
+        *(bf16x4*)(krow + d * 16) = bf16x4{(bf16_t)(dk[d][0] * os), (bf16_t)(dk[d][1] * os), (bf16_t)(dk[d][2] * os), (bf16_t)(dk[d][3] * os)};
+        *(bf16x4*)(vrow + d * 16) = bf16x4{(bf16_t)(dv[d][0] * ik), (bf16_t)(dv[d][1] * ik), (bf16_t)(dv[d][2] * ik), (bf16_t)(dv[d][3] * ik)};
+      }
+    }
+  }
+  // K goes where Q was.  Its rows are requested BEFORE the barrier (at most two 16-byte chunks per thread at every
+  // workgroup size the host uses), so a wave that finishes its key tiles early — or owns none — spends the wait for the
+  // others on this latency instead of after it.
+  static_assert(HD == 64, "delta reduction and K restaging assume 8 chunks per row");
+  bf16x8 kpre[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = tid + j * nthr, r = e >> 3, c8 = e & 7;
+    kpre[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (e < rows_live * 8 && r < S) kpre[j] = *(const bf16x8*)(qkv + D + r * tld + c8 * 8);
+  }
+  __syncthreads();   // every dS^T tile is in LDS; the Q / dO images are free
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = tid + j * nthr, r = e >> 3, c8 = e & 7;
+    if (e < rows_live * 8) *(bf16x8*)(img0 + r * V2_LD + c8 * 8) = kpre[j];
+  }
+  __syncthreads();
+  // ------------------------------------------------------------------ phase 2 (queries on lanes): dQ^T = K^T dS^T
+  for (int qt = wave; qt < n_tq; qt += nw) {
+    const int q = qt * 16 + c;
+    f32x4 dq[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int pk = 0; pk < n_pair_k; ++pk) {
+      const bf16x8 fs = v2_frag_tr_ld(dsT, ldq, 2 * pk, qt * 16, lane, 2 * pk + 1 < n_t);
+#pragma unroll
+      for (int d = 0; d < ND; ++d) dq[d] = mfma_bf16(v2_frag_tr(img0, 2 * pk, d * 16, lane), fs, dq[d]);
+    }
+    if (q < S) {
+      const float os = a.scale * ik;
+      bf16_t* orow = dqkv + (int64_t)q * gld + 4 * g;
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+        *(bf16x4*)(orow + d * 16) = bf16x4{(bf16_t)(dq[d][0] * os), (bf16_t)(dq[d][1] * os), (bf16_t)(dq[d][2] * os), (bf16_t)(dq[d][3] * os)};
+    }
+  }
+}
+
+// LDS of the one-pass kernel for rows of up to S keys; 0 = does not fit
+static size_t v4_lds_bytes(int S, int* rows_img, int* ldq) {
+  const int n_t = (S + 15) / 16;
+  *rows_img = ((n_t + 1) / 2) * 32;
+  *ldq = (n_t & 1) ? 16 * n_t : 16 * n_t + 16;        // ldq / 2 = 8 (mod 16) banks: rows 0-7 of a transposed read fall on distinct 8-bank groups
+  const size_t b = (size_t)2 * *rows_img * V2_LD * 2 + (size_t)3 * *rows_img * 4 + (size_t)16 * n_t * *ldq * 2;
+  return b <= 160 * 1024 ? b : 0;
+}
+
 template <bool STRUCT, bool DROP>
 static int launch_v3(hipStream_t st, const AttnParams& p) {
   const int s_pad = (p.f.S + 63) & ~63;
@@ -717,6 +932,28 @@ static int launch_v3(hipStream_t st, const AttnParams& p) {
     }
   }
   if constexpr (!STRUCT) {
+    // one-pass kernel wherever its dS image fits LDS (S <= 224); MDT_ATTN_ONEPASS=0 keeps the two-pass kernels.  In-call
+    // A/B with dropout 0.1 (tools/attn_onepass_ab.py): ViT rows (512 x 201) 755 -> 525 us, padded BERT rows (2048 x 104)
+    // 993 -> 792 us, ragged BERT rows (8-100 tokens) 592 -> 493 us; gradients equal to bf16 rounding of delta.
+    const int op = switches().attn_onepass;
+    int rows_img = 0, ldq = 0;
+    const size_t lds4 = v4_lds_bytes(p.f.S, &rows_img, &ldq);
+    if (lds4 && op != 0) {
+      auto k4 = attn_bwd_v4_kernel<64, DROP>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+          (void)hipGetLastError();
+          set_error("attention_bwd_v4: cannot reserve 160 KiB of LDS");
+          return MDT_ERR_LAUNCH;
+        }
+        attr_set = true;
+      }
+      const int n_t = (p.f.S + 15) / 16;
+      const int waves = n_t <= 4 ? 4 : n_t <= 8 ? 8 : 16;
+      hipLaunchKernelGGL(k4, dim3(p.f.H, p.f.nseq), waves * 64, lds4, st, p, rows_img, ldq);
+      return check_launch("attention_bwd_v4");
+    }
     if (s_pad <= 128 && !switches().attn_no_occ4) {
       hipLaunchKernelGGL((attn_bwd_v3_occ4_kernel<64, DROP>), dim3(p.f.H, p.f.nseq), 256, lds, st, p, s_pad);
       return check_launch("attention_bwd_v3_occ4");

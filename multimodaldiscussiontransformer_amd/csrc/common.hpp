@@ -52,6 +52,7 @@ struct Switches {
   char attn_bwd[8];          // MDT_ATTN_BWD       ("" unset)
   bool attn_no_occ4;         // MDT_ATTN_NO_OCC4
   bool attn_no_w8;           // MDT_ATTN_NO_W8
+  int attn_onepass;          // MDT_ATTN_ONEPASS   (0: two-pass backward kernels only; default: one-pass wherever its dS image fits LDS)
 };
 const Switches& switches();
 

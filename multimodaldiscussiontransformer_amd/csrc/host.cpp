@@ -55,6 +55,7 @@ static void read_switches() {
   str("MDT_ATTN_BWD", g_sw.attn_bwd, sizeof(g_sw.attn_bwd));
   g_sw.attn_no_occ4 = flag("MDT_ATTN_NO_OCC4");
   g_sw.attn_no_w8 = flag("MDT_ATTN_NO_W8");
+  g_sw.attn_onepass = num("MDT_ATTN_ONEPASS", -1);
   g_sw_valid = true;
 }
 
