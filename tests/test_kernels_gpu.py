@@ -576,6 +576,49 @@ def test_attention_query_limit(ops, dtype, S, H, qlim):
     torch.testing.assert_close(g_lim.float(), g_full.float(), **tol)
 
 
+# ----------------------------------------------------------------------------- one-pass backward against the two-pass kernels
+@pytest.mark.parametrize("S,ragged,qlim,p", [(201, False, 0, 0.1), (104, False, 0, 0.3), (104, True, 0, 0.1), (201, True, 0, 0.0),
+                                               (65, False, 33, 0.1), (224, False, 0, 0.1), (17, False, 0, 0.2)])
+def test_attention_backward_one_pass_equals_two_pass(ops, S, ragged, qlim, p, monkeypatch):
+    """csrc/attention_v2.hip attn_bwd_v4 (dS^T parked in LDS, dQ from a transposed read) against attn_bwd_v3 (S and dP
+    computed twice) on the same inputs and dropout masks: the same operands reach the same MFMAs, so the gradients may
+    differ only by the summation order of delta = rowsum(dO * O)."""
+    from multimodaldiscussiontransformer_amd import _lib as L
+    nseq, H, hd = 5, 3, 64
+    g = torch.Generator().manual_seed(S + 7)
+    kw = dict(drop_p=p, drop_seed=11)
+    if ragged:
+        lens = torch.randint(1, S + 1, (nseq,), generator=g, dtype=torch.int32)
+        lens[0] = S
+        off = torch.zeros(nseq + 1, dtype=torch.int32)
+        off[1:] = torch.cumsum(lens, 0)
+        rows = int(off[-1])
+        kw["seq_offsets"] = dev(off)
+    else:
+        rows = nseq * S
+    if qlim:
+        kw["q_limit"] = qlim
+    qkv = dev((torch.randn(rows, 3 * H * hd, generator=g) * 0.7).to(torch.bfloat16))
+    dout = dev(torch.randn(rows, H * hd, generator=g).to(torch.bfloat16))
+    out, lse = ops.attention_fwd(qkv, nseq, S, H, **kw)
+    grads = []
+    try:
+        for v in ("0", "1"):
+            monkeypatch.setenv("MDT_ATTN_BWD", "v3")
+            monkeypatch.setenv("MDT_ATTN_ONEPASS", v)
+            L.reload_env()
+            d, _ = ops.attention_bwd(dout, qkv, out, lse, nseq, S, H, **kw)
+            grads.append(d.float().cpu())
+    finally:
+        monkeypatch.delenv("MDT_ATTN_BWD")
+        monkeypatch.delenv("MDT_ATTN_ONEPASS")
+        L.reload_env()
+    assert torch.isfinite(grads[1]).all()
+    scale = grads[0].abs().max().item()
+    assert (grads[0] - grads[1]).abs().max().item() <= 8e-3 * max(scale, 1.0)
+    assert ((grads[0] - grads[1]).norm() / grads[0].norm()).item() <= 1e-3
+
+
 # ----------------------------------------------------------------------------- error behaviour of the C ABI
 def test_abi_rejects_bad_arguments_loudly(ops):
     """Every entry point returns a negative status (raised as MdtError with the library's message) instead of
