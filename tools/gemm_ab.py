@@ -54,6 +54,14 @@ def combos(M):
     out.append(("dfc1 NT      res", x3072, r(3072, 768), dict(trans_b=True, residual=r(M, 768))))
     out.append(("dfc2 NT      mulaux+colsum", x768, r(768, 3072), dict(trans_b=True, aux=r(M, 3072), epilogue=ops.EPI_MULAUX,
                                                                      colsum=torch.zeros(3072, device=dev))))
+    if "--epi" in sys.argv:      # what the epilogue variants cost on one short-K shape (N = K = 768)
+        out = []
+        w, wt = r(768, 768), r(768, 768)
+        out.append(("NN plain(generic)", x768, w, dict()))
+        out.append(("NN bias", x768, w, dict(bias=r(768))))
+        out.append(("NN bias+res+drop", x768, w, dict(bias=r(768), residual=r(M, 768), drop_p=0.4, drop_seed=3)))
+        out.append(("NT plain", x768, wt, dict(trans_b=True)))
+        out.append(("NT res", x768, wt, dict(trans_b=True, residual=r(M, 768))))
     return out
 
 
