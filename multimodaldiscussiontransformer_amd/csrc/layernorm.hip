@@ -22,6 +22,9 @@ template <> struct Vec<bf16_t> {
 };
 
 // NV = number of 16-B vectors per lane: D = NV * 64 * Vec<T>::N exactly, or masked tail.
+// A wave walks rows wid, wid + nwaves, ...; the next row is requested before the current one is reduced, so a wave keeps
+// two rows (and an 8-workgroup CU 64 of them, ~100 KiB) in flight — with one row per wave and no look-ahead the kernel
+// moved 4.1 TB/s, bounded by bytes in flight over the ~2 us of an HBM round trip.
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int D, const T* __restrict__ x, int64_t ldx,
                                                             const T* __restrict__ gamma, const T* __restrict__ beta,
@@ -29,50 +32,71 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int D,
                                                             float* __restrict__ mean, float* __restrict__ rstd) {
   constexpr int VN = Vec<T>::N;
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const T* xr = x + row * ldx;
-  Vec<T> xv[NV];
-  float s = 0.f;
+  Vec<T> gv[NV], bv[NV], xv[NV], xn[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * VN;
     if (c < D) {
-      xv[i] = *(const Vec<T>*)(xr + c);
-#pragma unroll
-      for (int j = 0; j < VN; ++j) s += xv[i].get(j);
+      xv[i] = *(const Vec<T>*)(x + row * ldx + c);
+      gv[i] = *(const Vec<T>*)(gamma + c);
+      bv[i] = *(const Vec<T>*)(beta + c);
     }
   }
-  const float mu = wave_sum(s) / (float)D;
-  float q = 0.f;
+  for (;;) {
+    const int64_t next = row + nwaves;
+    if (next < rows) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = (i * 64 + lane) * VN;
-    if (c < D) {
-#pragma unroll
-      for (int j = 0; j < VN; ++j) { const float d = xv[i].get(j) - mu; q += d * d; }
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * VN;
+        if (c < D) xn[i] = *(const Vec<T>*)(x + next * ldx + c);
+      }
     }
-  }
-  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
-  if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
-  T* yr = y + row * ldy;
+    float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = (i * 64 + lane) * VN;
-    if (c < D) {
-      const Vec<T> g = *(const Vec<T>*)(gamma + c);
-      const Vec<T> b = *(const Vec<T>*)(beta + c);
-      Vec<T> o;
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * VN;
+      if (c < D) {
 #pragma unroll
-      for (int j = 0; j < VN; ++j) o.set(j, (xv[i].get(j) - mu) * rs * g.get(j) + b.get(j));
-      *(Vec<T>*)(yr + c) = o;
+        for (int j = 0; j < VN; ++j) s += xv[i].get(j);
+      }
     }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * VN;
+      if (c < D) {
+#pragma unroll
+        for (int j = 0; j < VN; ++j) { const float d = xv[i].get(j) - mu; q += d * d; }
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+    T* yr = y + row * ldy;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * VN;
+      if (c < D) {
+        Vec<T> o;
+#pragma unroll
+        for (int j = 0; j < VN; ++j) o.set(j, (xv[i].get(j) - mu) * rs * gv[i].get(j) + bv[i].get(j));
+        *(Vec<T>*)(yr + c) = o;
+      }
+    }
+    if (next >= rows) break;
+    row = next;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) xv[i] = xn[i];
   }
 }
 
-// Backward: each wave walks rows_per_wave consecutive rows, keeps per-lane partial
-// dgamma / dbeta in registers, the block combines them through LDS and issues one
-// float atomic per column.
+// Backward: each wave walks rows_per_wave consecutive rows (the next row's x / dy / residual-gradient vectors are
+// requested before the current row is reduced), keeps per-lane partial dgamma / dbeta / column sums in registers,
+// the block combines them through ONE [4 waves][row] LDS buffer used three times (16 KiB at D = 768: the 48 KiB of
+// three buffers held a CU to three workgroups) and issues one float atomic per column.
 template <typename T, int NV, bool TAIL>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D, const T* __restrict__ dy, int64_t lddy,
                                                             const T* __restrict__ x, int64_t ldx,
@@ -84,7 +108,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
                                                             DropCfg drop, float* __restrict__ colsum) {
   constexpr int VN = Vec<T>::N;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* red = (float*)smem_raw;  // [3][4 waves][NV*64*VN]
+  float* red = (float*)smem_raw;  // [4 waves][NV*64*VN]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
   const int64_t r1 = (r0 + rows_per_wave < rows) ? r0 + rows_per_wave : rows;
@@ -97,16 +121,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
 #pragma unroll
     for (int j = 0; j < VN; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; pc[i][j] = 0.f; }
   }
+  Vec<T> xv[NV], gy[NV], av[NV], xn[NV], gn[NV], an[NV];
+  float mu = 0.f, rs = 0.f, mu_n = 0.f, rs_n = 0.f;
+  if (r0 < r1) {
+    mu = mean[r0]; rs = rstd[r0];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * VN;
+      if (c < D) {
+        xv[i] = *(const Vec<T>*)(x + r0 * ldx + c);
+        gy[i] = *(const Vec<T>*)(dy + r0 * lddy + c);
+        if (add) av[i] = *(const Vec<T>*)(add + r0 * ldadd + c);
+      }
+    }
+  }
   for (int64_t row = r0; row < r1; ++row) {
-    const float mu = mean[row], rs = rstd[row];
-    Vec<T> xv[NV], gy[NV];
+    if (row + 1 < r1) {
+      mu_n = mean[row + 1]; rs_n = rstd[row + 1];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * VN;
+        if (c < D) {
+          xn[i] = *(const Vec<T>*)(x + (row + 1) * ldx + c);
+          gn[i] = *(const Vec<T>*)(dy + (row + 1) * lddy + c);
+          if (add) an[i] = *(const Vec<T>*)(add + (row + 1) * ldadd + c);
+        }
+      }
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * VN;
       if (c < D) {
-        xv[i] = *(const Vec<T>*)(x + row * ldx + c);
-        gy[i] = *(const Vec<T>*)(dy + row * lddy + c);
 #pragma unroll
         for (int j = 0; j < VN; ++j) {
           const float xh = (xv[i].get(j) - mu) * rs;
@@ -124,14 +170,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * VN;
       if (c < D) {
-        Vec<T> o, od, a;
+        Vec<T> o, od;
         float ds0 = 0.f, ds1 = 0.f;
-        if (add) a = *(const Vec<T>*)(add + row * ldadd + c);
 #pragma unroll
         for (int j = 0; j < VN; ++j) {
           const float xh = (xv[i].get(j) - mu) * rs;
           float v = rs * (gy[i].get(j) * gv[i].get(j) - m1 - xh * m2);
-          if (add) v += a.get(j);
+          if (add) v += av[i].get(j);
           o.set(j, v);
           if constexpr (TAIL) {
             if (dxd) {   // second output: the gradient of the dense layer behind a hidden dropout
@@ -151,27 +196,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
         }
       }
     }
+    mu = mu_n; rs = rs_n;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { xv[i] = xn[i]; gy[i] = gn[i]; av[i] = an[i]; }
   }
   if (!dgamma && !dbeta && !colsum) return;
   const int W = NV * 64 * VN;
+  // three rounds through the one buffer: dgamma, dbeta, column sums
 #pragma unroll
-  for (int i = 0; i < NV; ++i)
+  for (int round = 0; round < (TAIL ? 3 : 2); ++round) {
+    float* dst = round == 0 ? dgamma : round == 1 ? dbeta : colsum;
+    if (round) __syncthreads();           // the previous round's readers are done
 #pragma unroll
-    for (int j = 0; j < VN; ++j) {
-      const int c = (i * 64 + lane) * VN + j;
-      red[wave * W + c] = pg[i][j];
-      red[(4 + wave) * W + c] = pb[i][j];
-      if constexpr (TAIL) red[(8 + wave) * W + c] = pc[i][j];
-    }
-  __syncthreads();
-  for (int c = threadIdx.x; c < D; c += 256) {
-    const float g = red[c] + red[W + c] + red[2 * W + c] + red[3 * W + c];
-    const float b = red[4 * W + c] + red[5 * W + c] + red[6 * W + c] + red[7 * W + c];
-    if (dgamma) atomicAdd(dgamma + c, g);
-    if (dbeta) atomicAdd(dbeta + c, b);
-    if constexpr (TAIL) {
-      if (colsum) atomicAdd(colsum + c, red[8 * W + c] + red[9 * W + c] + red[10 * W + c] + red[11 * W + c]);
-    }
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = 0; j < VN; ++j) {
+        const int c = (i * 64 + lane) * VN + j;
+        red[wave * W + c] = round == 0 ? pg[i][j] : round == 1 ? pb[i][j] : pc[i][j];
+      }
+    __syncthreads();
+    if (dst)
+      for (int c = threadIdx.x; c < D; c += 256) atomicAdd(dst + c, red[c] + red[W + c] + red[2 * W + c] + red[3 * W + c]);
   }
 }
 
@@ -180,7 +225,9 @@ static int ln_fwd_dispatch(hipStream_t st, int64_t rows, int D, const void* x, i
                            const void* beta, float eps, void* y, int64_t ldy, float* mean, float* rstd) {
   constexpr int VN = Vec<T>::N;
   const int nv = (D + 64 * VN - 1) / (64 * VN);
-  const unsigned grid = (unsigned)((rows + 3) / 4);
+  // 8 resident workgroups per CU (32 waves, two rows in flight each); short inputs get one row per wave
+  const int64_t wgs = (rows + 3) / 4;
+  const unsigned grid = (unsigned)(wgs < 2048 ? wgs : 2048);
 #define LN_FWD(NV_)                                                                                          \
   hipLaunchKernelGGL((layernorm_fwd_kernel<T, NV_>), grid, 256, 0, st, rows, D, (const T*)x, ldx,          \
                      (const T*)gamma, (const T*)beta, eps, (T*)y, ldy, mean, rstd)
@@ -211,11 +258,11 @@ static int ln_bwd_dispatch(hipStream_t st, int64_t rows, int D, const void* dy, 
   const bool tail = dxd != nullptr || colsum != nullptr;
 #define LN_BWD(NV_)                                                                                              \
   if (tail)                                                                                                      \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV_, true>), grid, 256, (size_t)(12 * NV_ * 64 * VN * 4), st, rows, D, \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV_, true>), grid, 256, (size_t)(4 * NV_ * 64 * VN * 4), st, rows, D, \
                        (const T*)dy, lddy, (const T*)x, ldx, (const T*)gamma, mean, rstd, (const T*)add, ldadd,  \
                        (T*)dx, lddx, dgamma, dbeta, rpw, (T*)dxd, lddxd, drop, colsum);                          \
   else                                                                                                           \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV_, false>), grid, 256, (size_t)(8 * NV_ * 64 * VN * 4), st, rows, D, \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV_, false>), grid, 256, (size_t)(4 * NV_ * 64 * VN * 4), st, rows, D, \
                        (const T*)dy, lddy, (const T*)x, ldx, (const T*)gamma, mean, rstd, (const T*)add, ldadd,  \
                        (T*)dx, lddx, dgamma, dbeta, rpw, (T*)dxd, lddxd, drop, colsum)
   switch (nv) {
