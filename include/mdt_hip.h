@@ -52,6 +52,11 @@ enum {
                             (GELU'(u), times the dropout scale of the element when MDT_EPI_DROPOUT is set)
                             instead of u — the backward pass is then a plain MDT_EPI_MULAUX */
   MDT_EPI_MULAUX = 512,  /* * aux[m, n] (backward of an epilogue that saved its derivative) */
+  MDT_EPI_ASUM = 1024,   /* colsum[m] += sum_k op(A)[m, k] (fp32 atomics): with trans_a = 1 the column sums of the STORED
+                            A — the bias gradient db = colsum(dY) riding on the weight-gradient GEMM dW = dY^T X that
+                            streams dY anyway (one extra MFMA against a vector of ones per A fragment, in the workgroups
+                            of the first tile column only).  Needs trans_a = 1, MDT_EPI_ATOMIC and a colsum buffer of M
+                            floats; excludes MDT_EPI_COLSUM (the two share the buffer argument) */
   MDT_EPI_DROPOUT = 64   /* inverted dropout on the value after bias / GELU and before the residual add
                             (with MDT_EPI_DGELU: on the incoming gradient, before the GELU' factor);
                             element (m, n) of site `drop_seed` uses counter m*N + n */

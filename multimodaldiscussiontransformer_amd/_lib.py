@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libmdt_hip.so")
 
 MDT_F32, MDT_BF16 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_ACCUM, EPI_ATOMIC, EPI_DROPOUT, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64, 128
-EPI_AUX_GRAD, EPI_MULAUX = 256, 512
+EPI_AUX_GRAD, EPI_MULAUX, EPI_ASUM = 256, 512, 1024
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 

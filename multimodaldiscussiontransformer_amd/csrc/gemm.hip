@@ -812,6 +812,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // MDT_EPI_ASUM (weight gradients): the workgroups of tile column 0 also sum op(A) over k — each of the four waves
+  // that hold the same A fragments takes two of the eight row tiles against a B fragment of ones
+  const bool asum = !SWAP && (p.epilogue & MDT_EPI_ASUM) && tn == 0;
+  f32x4 accb0 = f32x4{0.f, 0.f, 0.f, 0.f}, accb1 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16x8 ones = bf16x8{(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
 
   // step hs (32 k) -> ring buffer `buf`: 4 LDS-DMA pieces per wave (2 of A, 2 of B)
   auto issue_step = [&](int hs, int buf) {
@@ -860,6 +865,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = SWAP ? mfma_bf16(b[j], a[i], acc[i][j]) : mfma_bf16(a[i], b[j], acc[i][j]);
+    if (asum) {
+      if (wc == 0) { accb0 = mfma_bf16(a[0], ones, accb0); accb1 = mfma_bf16(a[1], ones, accb1); }
+      else if (wc == 1) { accb0 = mfma_bf16(a[2], ones, accb0); accb1 = mfma_bf16(a[3], ones, accb1); }
+      else if (wc == 2) { accb0 = mfma_bf16(a[4], ones, accb0); accb1 = mfma_bf16(a[5], ones, accb1); }
+      else { accb0 = mfma_bf16(a[6], ones, accb0); accb1 = mfma_bf16(a[7], ones, accb1); }
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -878,6 +889,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
   if constexpr (SWAP) {
     direct_epilogue<2>(p, acc, lane, m0 + wr * 128, n0 + wc * 64);
     return;
+  }
+  if (asum && (lane & 15) == 0) {      // every column of the ones product holds the row sum: column 0 reports it
+    const int64_t mr = m0 + wr * 128 + wc * 32 + 4 * (lane >> 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (mr + r < p.M) atomicAdd(p.colsum + mr + r, p.alpha * accb0[r]);
+      if (mr + 16 + r < p.M) atomicAdd(p.colsum + mr + 16 + r, p.alpha * accb1[r]);
+    }
   }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -1527,8 +1546,17 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   p.group_n = 1 << 30;   // row-major unless launch_pp256 decides otherwise
   p.epilogue |= switches().gemm_diag << 20;   // diagnostics: 1 skip stores, 2 sc1 stores, 4 skewed starts, 8 every tile loads tile (0,0)'s panels
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_COLSUM) || (colsum && split_k == 1), "mdt_gemm: MDT_EPI_COLSUM needs a colsum buffer and split_k == 1");
+  MDT_CHECK_ARG(!(epilogue & MDT_EPI_ASUM) || (colsum && trans_a && (epilogue & MDT_EPI_ATOMIC) && !(epilogue & MDT_EPI_COLSUM) && dtype == MDT_BF16),
+                "mdt_gemm: MDT_EPI_ASUM needs bf16 operands, trans_a = 1, MDT_EPI_ATOMIC, a colsum buffer and no MDT_EPI_COLSUM");
   // tile128 contract: bf16, output dims that are tiled along a contiguous axis must be
   // whole tiles, 16-B aligned rows.
+  // MDT_EPI_ASUM rides on the 256 x 256 ping-pong kernel only; every other path sums the stored A ([K, M]) with the
+  // column-sum kernel first and runs without the flag
+  auto strip_asum = [&]() -> int {
+    if (!(p.epilogue & MDT_EPI_ASUM)) return MDT_OK;
+    p.epilogue &= ~MDT_EPI_ASUM;
+    return mdt_colsum(stream, dtype, K, M, A, lda, colsum, nullptr);
+  };
   bool fast = dtype == MDT_BF16 && K > 0;
   if (fast) {
     const bool a_ok = trans_a ? (M % T_BM == 0) : (K % T_BK == 0);
@@ -1572,9 +1600,11 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
       const bool pp = force ? !strcmp(force, "pp") : !switches().gemm_no_pp;
       if (pp) return out_dtype == MDT_F32 ? launch_pp256<float>(st, p, trans_a, trans_b)
                                           : launch_pp256<bf16_t>(st, p, trans_a, trans_b);
+      if (int e = strip_asum()) return e;
       return out_dtype == MDT_F32 ? launch_tile256<float, 256, 2, 4, 2>(st, p, trans_a, trans_b)
                                   : launch_tile256<bf16_t, 256, 2, 4, 2>(st, p, trans_a, trans_b);
     }
+    if (int e = strip_asum()) return e;
     if (use256x128) {
       p.tiles_m = (int)((M + 255) / 256);
       return out_dtype == MDT_F32 ? launch_tile256<float, 128, 4, 2, 3>(st, p, trans_a, trans_b)
@@ -1583,6 +1613,7 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
     return out_dtype == MDT_F32 ? launch_tile128<float>(st, p, trans_a, trans_b)
                                 : launch_tile128<bf16_t>(st, p, trans_a, trans_b);
   }
+  if (int e = strip_asum()) return e;
   int64_t chunk = ((K + split_k - 1) / split_k + 15) / 16 * 16;
   if (chunk < 16) chunk = 16;
   p.k_chunk = chunk;

@@ -16,6 +16,8 @@ temporaries that are handed back to autograd as ordinary ``.grad``s.
 """
 from __future__ import annotations
 
+import os
+
 import contextlib
 import threading
 from dataclasses import dataclass
@@ -260,13 +262,20 @@ def _split_k(n_out: int, k_out: int, red: int) -> int:
     return int(max(1, min(s, red // 1024 if red >= 1024 else 1)))
 
 
+_WGRAD_ASUM = os.environ.get("MDT_WGRAD_ASUM", "1") != "0"     # 0: separate column-sum launches (A/B runs)
+
+
 def wgrad(tape: Tape, dy: torch.Tensor, x: torch.Tensor, w: torch.nn.Parameter, b: Optional[torch.nn.Parameter]):
     """dW[N,K] += dY^T X (fp32, split-K atomics) and db[N] += colsum(dY)."""
     gw = tape.pgrad(w)
-    if gw is not None:
-        ops.gemm(dy, x, trans_a=True, trans_b=True, out=gw.view(dy.shape[1], x.shape[1]), epilogue=ops.EPI_ATOMIC,
-                 split_k=_split_k(dy.shape[1], x.shape[1], dy.shape[0]))
     gb = tape.pgrad(b) if b is not None else None
+    if gw is not None:
+        # the bias gradient rides on the weight-gradient GEMM, which streams dY anyway (MDT_EPI_ASUM; bf16 operands)
+        ride = gb is not None and dy.dtype == torch.bfloat16 and _WGRAD_ASUM
+        ops.gemm(dy, x, trans_a=True, trans_b=True, out=gw.view(dy.shape[1], x.shape[1]), epilogue=ops.EPI_ATOMIC,
+                 split_k=_split_k(dy.shape[1], x.shape[1], dy.shape[0]), asum=gb.view(-1) if ride else None)
+        if ride:
+            return
     if gb is not None:
         ops.colsum(dy, out=gb.view(-1))
 

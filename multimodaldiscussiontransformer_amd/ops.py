@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib as L
-from ._lib import (EPI_ACCUM, EPI_ATOMIC, EPI_AUX_GRAD, EPI_BIAS, EPI_COLSUM, EPI_DGELU, EPI_DROPOUT, EPI_GELU, EPI_MULAUX, EPI_RESIDUAL, check, dt, lib,
+from ._lib import (EPI_ACCUM, EPI_ASUM, EPI_ATOMIC, EPI_AUX_GRAD, EPI_BIAS, EPI_COLSUM, EPI_DGELU, EPI_DROPOUT, EPI_GELU, EPI_MULAUX, EPI_RESIDUAL, check, dt, lib,
                    ptr, stream)
 
 __all__ = [
@@ -19,7 +19,7 @@ __all__ = [
     "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "attention_mean_probs", "graph_attn_bias",
     "row_axpby", "row_scatter_add", "bert_embed_sum", "vit_patchify", "vit_assemble", "graph_node_feature",
     "tanh_fwd", "tanh_bwd", "node_ce", "contrastive_loss", "fp8_quantize", "fp8_scale_update", "gemm_fp8", "cast", "transpose2d", "dropout", "dropout_mask",
-    "EPI_BIAS", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_ACCUM", "EPI_ATOMIC", "EPI_DROPOUT", "EPI_AUX_GRAD", "EPI_MULAUX",
+    "EPI_BIAS", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_ACCUM", "EPI_ATOMIC", "EPI_DROPOUT", "EPI_AUX_GRAD", "EPI_MULAUX", "EPI_ASUM",
 ]
 
 
@@ -30,8 +30,10 @@ def _2d(t: torch.Tensor):
 
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out: Optional[torch.Tensor] = None,
          out_dtype=None, bias=None, residual=None, aux=None, epilogue=0, alpha=1.0, split_k=1, drop_p=0.0,
-         drop_seed=0, colsum=None) -> torch.Tensor:
-    """out[M,N] = epilogue(alpha * op(a) @ op(b)); b is [N,K] unless trans_b (then [K,N])."""
+         drop_seed=0, colsum=None, asum=None) -> torch.Tensor:
+    """out[M,N] = epilogue(alpha * op(a) @ op(b)); b is [N,K] unless trans_b (then [K,N]).
+    ``asum`` (fp32[M], with trans_a and EPI_ATOMIC): += the column sums of the stored ``a`` — a bias gradient riding
+    on the weight-gradient GEMM (MDT_EPI_ASUM)."""
     lda, ldb = _2d(a), _2d(b)
     M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
     N = b.shape[1] if trans_b else b.shape[0]
@@ -54,6 +56,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
     if colsum is not None:
         epilogue |= EPI_COLSUM
         assert colsum.dtype == torch.float32 and colsum.numel() == N
+    if asum is not None:
+        assert colsum is None and trans_a and asum.dtype == torch.float32 and asum.numel() == M and asum.is_contiguous()
+        epilogue |= EPI_ASUM
+        colsum = asum
     check(lib.mdt_gemm(stream(), dt(a), dt(out), int(trans_a), int(trans_b), M, N, K, ptr(a), lda, ptr(b), ldb,
                        ptr(out), _2d(out), epilogue, float(alpha), ptr(bias), ptr(residual),
                        _2d(residual) if residual is not None else 0, ptr(aux), _2d(aux) if aux is not None else 0,

@@ -107,6 +107,21 @@ def test_gemm_bf16_wgrad_splitk_and_epilogues(ops):
     torch.testing.assert_close(out.float().cpu(), u + res.float(), atol=0.03, rtol=1e-2)
 
 
+@pytest.mark.parametrize("rows,N,K,split", [(9000, 2304, 768, 5), (4100, 768, 3072, 3), (1000, 256, 128, 4), (300, 2304, 768, 1)])
+def test_gemm_wgrad_with_bias_gradient_riding(ops, rows, N, K, split):
+    """MDT_EPI_ASUM: db = colsum(dY) accumulated by the weight-gradient GEMM dW = dY^T X itself (256 x 256 ping-pong
+    kernel: one MFMA against ones per A fragment in tile column 0) or, on every other path, by the column-sum kernel
+    the entry point runs first.  Both outputs ACCUMULATE into what the buffers held."""
+    dy, x = rnd(rows, N, seed=21).bfloat16(), rnd(rows, K, seed=22).bfloat16()
+    w0, b0 = rnd(N, K, seed=23), rnd(N, seed=24)
+    gw, gb = dev(w0.clone()), dev(b0.clone())
+    ops.gemm(dev(dy), dev(x), trans_a=True, trans_b=True, out=gw, epilogue=ops.EPI_ATOMIC, split_k=split, asum=gb)
+    ref_w = w0 + dy.float().t() @ x.float()
+    ref_b = b0 + dy.float().sum(0)
+    torch.testing.assert_close(gw.cpu(), ref_w, atol=2e-2, rtol=1e-4)
+    torch.testing.assert_close(gb.cpu(), ref_b, atol=2e-3 * (rows ** 0.5), rtol=1e-4)
+
+
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_gemm_bf16_tile256_pipeline(ops, ta, tb):
     """Shapes large enough for the 256x128 three-stage kernel (>= 256 tiles), ragged M tail,
