@@ -165,6 +165,15 @@ typedef struct {
                                  (keys / values are always the whole sequence): forward leaves `out` / `lse` of the other rows
                                  unspecified, backward assumes their `dout` is zero and returns dQ = 0 for them.  Kernels may
                                  round n up (they work in 16-row tiles) or ignore it. */
+  const int32_t* seq_ids;     /* NULL, or i32[nseq] (ragged bf16 launches only): this launch covers the sequences
+                                 seq_ids[0 .. nseq) of a ragged set of `nseq_total` sequences — seq_offsets has nseq_total + 1
+                                 entries, lse is [nseq_total, H, S] and the dropout counters use the sequence's own index, so a
+                                 set may be processed as several launches (length bins) with bit-identical results. */
+  int s_cap;                  /* 0, or: no sequence of THIS launch is longer than s_cap (<= S) rows.  Kernels size their LDS
+                                 images and unrolled key loops by it instead of by S (a bin of short comments then runs the
+                                 small kernels); S keeps defining the lse / dropout-counter geometry.  A longer sequence is
+                                 skipped, not computed wrongly — the caller's host-side lengths are the contract. */
+  int nseq_total;             /* with seq_ids: size of the whole ragged set (0 = nseq) */
 } mdt_attn_fwd_args;
 int mdt_attention_fwd(void* stream, const mdt_attn_fwd_args* a);
 

@@ -29,6 +29,7 @@ class AttnFwdArgs(C.Structure):
         ("key_mask", _vp), ("dense_bias", _vp), ("attn_bias", _vp), ("spatial_pos", _vp),
         ("sp_table", _vp), ("virt", _vp), ("key_pad", _vp), ("num_spatial", _i),
         ("drop_p", _f), ("drop_seed", C.c_uint64), ("seq_offsets", _vp), ("q_limit", _i),
+        ("seq_ids", _vp), ("s_cap", _i), ("nseq_total", _i),
     ]
 
 

@@ -593,6 +593,14 @@ template <bool BWD>
 static int dispatch(hipStream_t st, const AttnParams& p) {
   const mdt_attn_fwd_args& a = p.f;
   const bool st_bias = a.attn_bias != nullptr;
+  const bool binned = a.seq_ids != nullptr || a.s_cap > 0;        // length bins of a ragged set: the v2 forward / v3-v4 backward only
+  if (binned) {
+    if (a.S > 272 || a.dtype != MDT_BF16 || a.hd != 64 || !a.seq_offsets || switches().attn_v1) {
+      set_error("attention: seq_ids / s_cap are for ragged bf16 launches with head_dim 64 and S <= 272");
+      return MDT_ERR_UNSUPPORTED;
+    }
+    return BWD ? attention_v3_bwd_dispatch(st, p) : attention_v2_dispatch(st, p, false);
+  }
   if (a.S > 272) return attention_long_dispatch(st, p, BWD);      // discussion trees with more than 271 comments
   if (a.dtype == MDT_BF16) {
     // a plain dense bias (no structural terms) is only handled by the kernels in this file
@@ -631,7 +639,10 @@ static int check_args(const mdt_attn_fwd_args& a) {
   if (a.seq_offsets)
     MDT_CHECK_ARG(a.pos_stride == 1 && !a.key_mask && !a.key_pad && !a.dense_bias && !a.attn_bias,
                   "attention: ragged sequences (seq_offsets) take no masks / biases and need pos_stride == 1");
-  MDT_CHECK_ARG(a.drop_p == 0.f || (uint64_t)a.nseq * a.H * a.S * (a.S + 1) < (1ull << 32),
+  MDT_CHECK_ARG(a.s_cap >= 0 && a.s_cap <= a.S, "attention: s_cap=%d outside [0, S=%d]", a.s_cap, a.S);
+  MDT_CHECK_ARG(!a.seq_ids || (a.seq_offsets && (a.nseq_total == 0 || a.nseq_total >= a.nseq)),
+                "attention: seq_ids need seq_offsets (and nseq_total >= nseq)");
+  MDT_CHECK_ARG(a.drop_p == 0.f || (uint64_t)(a.nseq_total > a.nseq ? a.nseq_total : a.nseq) * a.H * a.S * (a.S + 1) < (1ull << 32),
                 "attention: dropout counters are 32-bit (nseq*H*S*(S+1) must stay below 2^32)");
   return MDT_OK;
 }

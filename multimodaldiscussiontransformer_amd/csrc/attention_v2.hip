@@ -77,10 +77,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_v2_kernel(AttnParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mdt_attn_fwd_args& a = P.f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.x, seq = blockIdx.y;
+  const int h = blockIdx.x, seq = a.seq_ids ? a.seq_ids[blockIdx.y] : (int)blockIdx.y;
   const int SL = a.S, D = a.H * HD;                      // SL: lse / dropout-counter geometry
   const int S = a.seq_offsets ? a.seq_offsets[seq + 1] - a.seq_offsets[seq] : a.S;   // this sequence's length
   const int64_t row0 = a.seq_offsets ? (int64_t)a.seq_offsets[seq] : (int64_t)seq * a.seq_stride;
+  if (S > NT * 16) return;      // longer than this launch's bound (s_cap): never index past the images
   const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * a.ld_qkv + h * HD;
   const int64_t tld = a.pos_stride * a.ld_qkv;
   bf16_t* imgK = (bf16_t*)smem;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void attn_bwd_v2_kernel(AttnParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mdt_attn_fwd_args& a = P.f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.x, seq = blockIdx.y;
+  const int h = blockIdx.x, seq = a.seq_ids ? a.seq_ids[blockIdx.y] : (int)blockIdx.y;
   const int SL = a.S, D = a.H * HD;                      // SL: lse / dropout-counter geometry
   const int S = a.seq_offsets ? a.seq_offsets[seq + 1] - a.seq_offsets[seq] : a.S;   // this sequence's length
   const int64_t row0 = a.seq_offsets ? (int64_t)a.seq_offsets[seq] : (int64_t)seq * a.seq_stride;
@@ -418,7 +419,7 @@ __device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad)
   const mdt_attn_fwd_args& a = P.f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthr = blockDim.x, nw = nthr >> 6;      // 4 waves, or 8 for long sequences in the 128-register build
-  const int h = blockIdx.x, seq = blockIdx.y;
+  const int h = blockIdx.x, seq = a.seq_ids ? a.seq_ids[blockIdx.y] : (int)blockIdx.y;
   const int SL = a.S, D = a.H * HD;                      // SL: lse / dropout-counter geometry
   const int S = a.seq_offsets ? a.seq_offsets[seq + 1] - a.seq_offsets[seq] : a.S;   // this sequence's length
   const int64_t row0 = a.seq_offsets ? (int64_t)a.seq_offsets[seq] : (int64_t)seq * a.seq_stride;
@@ -437,6 +438,7 @@ __device__ __forceinline__ void attn_bwd_v3_body(const AttnParams& P, int s_pad)
   const int nhist = STRUCT ? ((a.num_spatial + 1 + 3) & ~3) : 0;
   BiasCtx bc{seq, h, S, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
   const int s_live = (S + 63) & ~63;                    // rows this (possibly ragged) sequence really uses, in 64-key chunks
+  if (s_live > s_pad) return;                           // longer than this launch's bound (s_cap)
   // Latency hiding (the waves of this kernel sat in s_waitcnt / s_barrier for half to two thirds of their cycles):
   // the Q / dO fragments of a wave's first query tile are requested before K / V are staged, and every later
   // tile's fragments while the previous tile is being computed; pass B treats its K / V fragments the same way.
@@ -733,7 +735,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
   const mdt_attn_fwd_args& a = P.f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthr = blockDim.x, nw = nthr >> 6;
-  const int h = blockIdx.x, seq = blockIdx.y;
+  const int h = blockIdx.x, seq = a.seq_ids ? a.seq_ids[blockIdx.y] : (int)blockIdx.y;
   const int SL = a.S, D = a.H * HD;
   const int S = a.seq_offsets ? a.seq_offsets[seq + 1] - a.seq_offsets[seq] : a.S;
   const int64_t row0 = a.seq_offsets ? (int64_t)a.seq_offsets[seq] : (int64_t)seq * a.seq_stride;
@@ -752,6 +754,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
   BiasCtx bc{seq, h, S, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
   const int n_t = (S + 15) >> 4;
   const int rows_live = ((n_t + 1) >> 1) * 32;         // this sequence's rows, in pairs of tiles (zero rows past S)
+  if (rows_live > rows_img) return;                    // longer than this launch's bound (s_cap)
   v2_stage<HD>(img0, qkv, tld, S, rows_live, tid, nthr);    // Q
   const float ik = DROP ? P.drop.inv_keep : 1.0f, rik = 1.0f / ik;
   // dO is staged by the same (row, 16-byte chunk) walk that forms delta = rowsum(dO * O): the 8 lanes of a row hold
@@ -919,10 +922,11 @@ static size_t v4_lds_bytes(int S, int* rows_img, int* ldq) {
 
 template <bool STRUCT, bool DROP>
 static int launch_v3(hipStream_t st, const AttnParams& p) {
-  const int s_pad = (p.f.S + 63) & ~63;
+  const int cap = p.f.s_cap > 0 ? p.f.s_cap : p.f.S;          // longest sequence of this launch
+  const int s_pad = (cap + 63) & ~63;
   const int nhist = STRUCT ? ((p.f.num_spatial + 1 + 3) & ~3) : 0;
   const size_t lds = (size_t)2 * s_pad * V2_LD * 2 + (size_t)3 * s_pad * 4 + (size_t)nhist * 4;
-  if (lds > 160 * 1024) { set_error("attention_bwd_v3: S=%d needs %zu bytes of LDS", p.f.S, lds); return MDT_ERR_UNSUPPORTED; }
+  if (lds > 160 * 1024) { set_error("attention_bwd_v3: S=%d needs %zu bytes of LDS", cap, lds); return MDT_ERR_UNSUPPORTED; }
   auto kern = attn_bwd_v3_kernel<64, STRUCT, DROP>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -937,7 +941,7 @@ static int launch_v3(hipStream_t st, const AttnParams& p) {
     // 993 -> 792 us, ragged BERT rows (8-100 tokens) 592 -> 493 us; gradients equal to bf16 rounding of delta.
     const int op = switches().attn_onepass;
     int rows_img = 0, ldq = 0;
-    const size_t lds4 = v4_lds_bytes(p.f.S, &rows_img, &ldq);
+    const size_t lds4 = v4_lds_bytes(cap, &rows_img, &ldq);
     if (lds4 && op != 0) {
       auto k4 = attn_bwd_v4_kernel<64, DROP>;
       static bool attr_set = false;
@@ -949,7 +953,7 @@ static int launch_v3(hipStream_t st, const AttnParams& p) {
         }
         attr_set = true;
       }
-      const int n_t = (p.f.S + 15) / 16;
+      const int n_t = (cap + 15) / 16;
       const int waves = n_t <= 4 ? 4 : n_t <= 8 ? 8 : 16;
       hipLaunchKernelGGL(k4, dim3(p.f.H, p.f.nseq), waves * 64, lds4, st, p, rows_img, ldq);
       return check_launch("attention_bwd_v4");
@@ -1006,9 +1010,9 @@ static int launch_v2(hipStream_t st, const AttnParams& p) {
 
 template <bool STRUCT, bool DROP, bool BWD>
 static int dispatch_v2_nt(hipStream_t st, const AttnParams& p) {
-  const int nt = (p.f.S + 15) / 16;
+  const int nt = ((p.f.s_cap > 0 ? p.f.s_cap : p.f.S) + 15) / 16;
 #define V2_CASE(N_) if (nt <= N_) return launch_v2<N_, STRUCT, DROP, BWD>(st, p);
-  V2_CASE(2) V2_CASE(5) V2_CASE(7) V2_CASE(9) V2_CASE(13) V2_CASE(17)
+  V2_CASE(2) V2_CASE(4) V2_CASE(5) V2_CASE(7) V2_CASE(9) V2_CASE(13) V2_CASE(17)
 #undef V2_CASE
   set_error("attention_v2: S=%d exceeds 272", p.f.S);
   return MDT_ERR_UNSUPPORTED;

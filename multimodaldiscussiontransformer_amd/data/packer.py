@@ -94,6 +94,27 @@ class RaggedText:
     types: torch.Tensor         # i32[T0]
     pos: torch.Tensor           # i32[T0]     original position of the token in its comment (position-embedding index)
     comment: torch.Tensor       # i32[T0]     comment index of the row
+    order: Optional[torch.Tensor] = None      # i32[M]   comment indices by increasing token count (stable)
+    sorted_lens: Optional["np.ndarray"] = None   # host int array [M]: the token counts in that order — lets the host cut
+    #                                             length bins (``length_bins``) without reading anything back from the device
+
+    def length_bins(self, extra: int, caps=(64,)):
+        """[(comment ids i32[n] (device), cap), ...]: the comments whose ``tokens + extra`` fit each cap, shortest bin
+        first, the rest under the overall maximum — attention then runs one launch per bin with the kernels that fit it
+        (ops.attention_fwd ``bins``).  None when there is nothing to cut (one bin would hold everything)."""
+        if self.order is None or self.sorted_lens is None:
+            return None
+        top = self.max_len + extra
+        cuts = [c for c in sorted(caps) if c < top]
+        if not cuts:
+            return None
+        bins, lo = [], 0
+        for c in cuts + [top]:
+            hi = int(np.searchsorted(self.sorted_lens, c - extra, side="right")) if c != top else int(self.sorted_lens.shape[0])
+            if hi > lo:
+                bins.append((self.order[lo:hi], int(c)))
+            lo = hi
+        return bins if len(bins) > 1 else None
 
 
 def ragged_text(ids: torch.Tensor, types: torch.Tensor, mask: torch.Tensor, device=None, non_blocking=True) -> RaggedText:
@@ -113,8 +134,10 @@ def ragged_text(ids: torch.Tensor, types: torch.Tensor, mask: torch.Tensor, devi
         t = t.to(torch.int32).contiguous()
         return t if device is None else t.to(device, non_blocking=non_blocking)
 
+    sl, order = torch.sort(lens, stable=True)
     return RaggedText(rows=int(src.numel()), max_len=int(lens.max()), offsets=to(off), ids=to(ids.reshape(-1)[src]),
-                      types=to(types.reshape(-1)[src]), pos=to(src - comment * Lq), comment=to(comment))
+                      types=to(types.reshape(-1)[src]), pos=to(src - comment * Lq), comment=to(comment), order=to(order),
+                      sorted_lens=sl.cpu().numpy().astype(np.int64))
 
 
 def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_blocking=True) -> PackedBatch:
@@ -224,7 +247,7 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
         node_row=pb.node_row, graph_row=pb.graph_row, degree=pb.degree, deg_scatter=pb.deg_scatter, key_pad=pb.key_pad,
         img_comment=pb.img_comment, label_rows=pb.label_rows, targets=pb.targets,
         rt_rows=rt.rows, rt_max_len=rt.max_len, rt_offsets=rt.offsets, rt_ids=rt.ids, rt_types=rt.types, rt_pos=rt.pos,
-        rt_comment=rt.comment)
+        rt_comment=rt.comment, rt_order=rt.order, rt_sorted_lens=rt.sorted_lens)
     return pb
 
 
@@ -251,7 +274,8 @@ def packed_from_batched_data(bd: dict) -> PackedBatch:
             img_comment=c["img_comment"], images=images, label_rows=c["label_rows"], targets=c["targets"],
             n_labels=c["n_labels"])
         pb.ragged = RaggedText(rows=c["rt_rows"], max_len=c["rt_max_len"], offsets=c["rt_offsets"], ids=c["rt_ids"],
-                               types=c["rt_types"], pos=c["rt_pos"], comment=c["rt_comment"])
+                               types=c["rt_types"], pos=c["rt_pos"], comment=c["rt_comment"], order=c.get("rt_order"),
+                               sorted_lens=c.get("rt_sorted_lens"))
         bd["_packed"] = pb
         return pb
     mask = bd["x_token_mask"]

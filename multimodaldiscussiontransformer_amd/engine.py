@@ -245,10 +245,11 @@ class AttnSpec:
     key_pad: Optional[torch.Tensor] = None         # u8[nseq,S]
     seq_offsets: Optional[torch.Tensor] = None     # i32[nseq+1]: ragged sequences of at most S rows (no masks / biases)
     q_limit: int = 0                               # > 0: only the first q_limit rows of every sequence are needed as queries
+    bins: Optional[list] = None                    # ragged: [(sequence ids i32[n], cap), ...] — one launch per length bin
 
     def kwargs(self):
         return dict(seq_stride=self.seq_stride, pos_stride=self.pos_stride, scale=self.scale, key_mask=self.key_mask,
-                    seq_offsets=self.seq_offsets, q_limit=self.q_limit,
+                    seq_offsets=self.seq_offsets, q_limit=self.q_limit, bins=self.bins,
                     dense_bias=self.dense_bias, attn_bias=self.attn_bias, spatial_pos=self.spatial_pos,
                     sp_table=None if self.sp_table is None else self.sp_table.data,
                     virt=None if self.virt is None else self.virt.data.view(-1), key_pad=self.key_pad)

@@ -120,6 +120,8 @@ class MultiGraphormerGraphEncoder(nn.Module):
         # valid-token packing of the text side (see _indices); MDT_DENSE_TOKENS=1 or ``ragged_tokens = False`` runs
         # the padded layout, which also reproduces the reference's hidden states at padded positions
         self.ragged_tokens = os.environ.get("MDT_DENSE_TOKENS", "0") != "1"
+        # ragged text attention as one launch per length bin (data/packer.py RaggedText.length_bins); MDT_LENGTH_BINS=0: one launch
+        self.length_bins = os.environ.get("MDT_LENGTH_BINS", "1") != "0"
         # logits path only (GraphormerModel.forward): the last fusion layer computes just the rows that are read
         # afterwards; MDT_FULL_LAST_LAYER=1 or ``prune_last_layer = False`` computes every row as the reference does
         self.prune_last_layer = os.environ.get("MDT_FULL_LAST_LAYER", "0") != "1"
@@ -206,8 +208,9 @@ class MultiGraphormerGraphEncoder(nn.Module):
             pre2fus = (torch.arange(rt.rows, **i32) + (rt.comment + 1) * nb).contiguous()
             rows_pre, rows_fus = rt.rows, rt.rows + M * nb
             S_pre, S_fus = rt.max_len, rt.max_len + nb
-            spec_pre = dict(S=S_pre, seq_offsets=off_pre)
-            spec_fus = dict(S=S_fus, seq_offsets=off_fus)
+            # comments of at most 64 rows (four key tiles) run the small attention kernels in a launch of their own
+            spec_pre = dict(S=S_pre, seq_offsets=off_pre, bins=rt.length_bins(0) if self.length_bins else None)
+            spec_fus = dict(S=S_fus, seq_offsets=off_fus, bins=rt.length_bins(nb) if self.length_bins else None)
         else:
             St = nb + Lq
             bn0 = (m_ar * St).contiguous()

@@ -110,7 +110,7 @@ class MultiheadAttention(QKVFusedMixin, nn.Module):
             # default); recomputed from q, k and the forward's log-sum-exp — the fused kernel never stores them.  Returned
             # detached: nothing in mDT differentiates through them.
             from .. import ops
-            kw = {k: v for k, v in stash["kw"].items() if k not in ("seq_offsets", "q_limit")}
+            kw = {k: v for k, v in stash["kw"].items() if k not in ("seq_offsets", "q_limit", "bins")}
             weights = ops.attention_mean_probs(stash["qkv"], stash["lse"], bsz, tgt_len, self.num_heads, **kw)
         return out.view(tgt_len, bsz, embed_dim), weights
 

@@ -106,7 +106,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, add=None, dgamma=None, dbeta=None, d
 
 
 def _attn_args(qkv, out, lse, nseq, S, H, hd, seq_stride, pos_stride, scale, key_mask, dense_bias, attn_bias,
-               spatial_pos, sp_table, virt, key_pad, drop_p=0.0, drop_seed=0, seq_offsets=None, q_limit=0):
+               spatial_pos, sp_table, virt, key_pad, drop_p=0.0, drop_seed=0, seq_offsets=None, q_limit=0, seq_ids=None, s_cap=0):
     a = L.AttnFwdArgs()
     a.q_limit = int(q_limit)
     a.drop_p, a.drop_seed = float(drop_p), int(drop_seed)
@@ -115,6 +115,10 @@ def _attn_args(qkv, out, lse, nseq, S, H, hd, seq_stride, pos_stride, scale, key
     a.seq_offsets = ptr(seq_offsets)
     a.dtype = dt(qkv)
     a.nseq, a.S, a.H, a.hd = nseq, S, H, hd
+    a.s_cap = int(s_cap)
+    if seq_ids is not None:        # one length bin of the ragged set: the launch covers these sequences only
+        assert seq_offsets is not None and seq_ids.dtype == torch.int32 and seq_ids.is_contiguous()
+        a.seq_ids, a.nseq, a.nseq_total = ptr(seq_ids), int(seq_ids.numel()), nseq
     a.seq_stride, a.pos_stride, a.scale = seq_stride, pos_stride, float(scale)
     a.qkv, a.ld_qkv = ptr(qkv), _2d(qkv)
     a.out, a.ld_out = ptr(out), _2d(out)
@@ -135,10 +139,12 @@ def _attn_args(qkv, out, lse, nseq, S, H, hd, seq_stride, pos_stride, scale, key
 
 def attention_fwd(qkv, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None, key_mask=None, dense_bias=None,
                   attn_bias=None, spatial_pos=None, sp_table=None, virt=None, key_pad=None, drop_p=0.0, drop_seed=0,
-                  seq_offsets=None, q_limit=0):
+                  seq_offsets=None, q_limit=0, bins=None):
     """qkv [rows, 3*D] → (out [rows, D], lse f32[nseq, H, S]).  ``q_limit`` > 0: only the first q_limit rows of every
     sequence are needed as queries (other rows of out / lse unspecified).  ``seq_offsets`` i32[nseq+1]: ragged sequences
-    (sequence s = rows off[s]..off[s+1], at most S of them), see include/mdt_hip.h."""
+    (sequence s = rows off[s]..off[s+1], at most S of them), see include/mdt_hip.h.  ``bins``: [(seq_ids i32[n], cap), ...]
+    — a partition of the ragged set by length (no sequence of a bin longer than its cap): one launch per bin, each with
+    the kernels that fit its cap; results are identical to the single launch."""
     D = qkv.shape[1] // 3
     hd = D // H
     if q_limit:
@@ -148,10 +154,15 @@ def attention_fwd(qkv, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None,
     else:
         out = torch.empty(qkv.shape[0], D, dtype=qkv.dtype, device=qkv.device)   # every row belongs to a sequence
         lse = torch.empty(nseq, H, S, dtype=torch.float32, device=qkv.device)
-    a = _attn_args(qkv, out, lse, nseq, S, H, hd, S if seq_stride is None else seq_stride, pos_stride,
-                   hd ** -0.5 if scale is None else scale, key_mask, dense_bias, attn_bias, spatial_pos, sp_table,
-                   virt, key_pad, drop_p, drop_seed, seq_offsets, q_limit)
-    check(lib.mdt_attention_fwd(stream(), C.byref(a)), "mdt_attention_fwd")
+    if bins is not None and (qkv.dtype != torch.bfloat16 or hd != 64 or S > 272):
+        bins = None                      # the binned launches exist for the bf16 head-dim-64 kernels only
+    for ids, cap in (bins or [(None, 0)]):
+        if ids is not None and ids.numel() == 0:
+            continue
+        a = _attn_args(qkv, out, lse, nseq, S, H, hd, S if seq_stride is None else seq_stride, pos_stride,
+                       hd ** -0.5 if scale is None else scale, key_mask, dense_bias, attn_bias, spatial_pos, sp_table,
+                       virt, key_pad, drop_p, drop_seed, seq_offsets, q_limit, ids, cap)
+        check(lib.mdt_attention_fwd(stream(), C.byref(a)), "mdt_attention_fwd")
     return out, lse
 
 
@@ -169,24 +180,30 @@ def attention_mean_probs(qkv, lse, nseq, S, H, *, seq_stride=None, pos_stride=1,
 
 def attention_bwd(dout, qkv, out, lse, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None, key_mask=None,
                   dense_bias=None, attn_bias=None, spatial_pos=None, sp_table=None, virt=None, key_pad=None,
-                  want_dense_dbias=False, d_sp_table=None, d_virt=None, drop_p=0.0, drop_seed=0, seq_offsets=None, q_limit=0):
+                  want_dense_dbias=False, d_sp_table=None, d_virt=None, drop_p=0.0, drop_seed=0, seq_offsets=None, q_limit=0,
+                  bins=None):
     D = qkv.shape[1] // 3
     hd = D // H
     # with q_limit the kernels skip the query rows beyond it: their dQ must read as zero
     dqkv = torch.zeros_like(qkv) if q_limit else torch.empty_like(qkv)
-    b = L.AttnBwdArgs()
-    b.f = _attn_args(qkv, out, lse, nseq, S, H, hd, S if seq_stride is None else seq_stride, pos_stride,
-                     hd ** -0.5 if scale is None else scale, key_mask, dense_bias, attn_bias, spatial_pos, sp_table,
-                     virt, key_pad, drop_p, drop_seed, seq_offsets, q_limit)
-    b.dout, b.ld_dout = ptr(dout), _2d(dout)
-    b.dqkv, b.ld_dqkv = ptr(dqkv), _2d(dqkv)
     dbias = None
     if want_dense_dbias:
         dbias = torch.zeros(nseq, H, S, S, dtype=torch.float32, device=qkv.device)
-    b.d_dense_bias = ptr(dbias)
-    b.d_sp_table = ptr(d_sp_table)
-    b.d_virt = ptr(d_virt)
-    check(lib.mdt_attention_bwd(stream(), C.byref(b)), "mdt_attention_bwd")
+    if bins is not None and (qkv.dtype != torch.bfloat16 or hd != 64 or S > 272):
+        bins = None
+    for ids, cap in (bins or [(None, 0)]):
+        if ids is not None and ids.numel() == 0:
+            continue
+        b = L.AttnBwdArgs()
+        b.f = _attn_args(qkv, out, lse, nseq, S, H, hd, S if seq_stride is None else seq_stride, pos_stride,
+                         hd ** -0.5 if scale is None else scale, key_mask, dense_bias, attn_bias, spatial_pos, sp_table,
+                         virt, key_pad, drop_p, drop_seed, seq_offsets, q_limit, ids, cap)
+        b.dout, b.ld_dout = ptr(dout), _2d(dout)
+        b.dqkv, b.ld_dqkv = ptr(dqkv), _2d(dqkv)
+        b.d_dense_bias = ptr(dbias)
+        b.d_sp_table = ptr(d_sp_table)
+        b.d_virt = ptr(d_virt)
+        check(lib.mdt_attention_bwd(stream(), C.byref(b)), "mdt_attention_bwd")
     return dqkv, dbias
 
 

@@ -634,6 +634,46 @@ def test_attention_backward_one_pass_equals_two_pass(ops, S, ragged, qlim, p, mo
     assert ((grads[0] - grads[1]).norm() / grads[0].norm()).item() <= 1e-3
 
 
+# ----------------------------------------------------------------------------- ragged attention in length bins
+@pytest.mark.parametrize("p,qlim", [(0.0, 0), (0.2, 0), (0.1, 20)])
+def test_attention_length_bins_equal_single_launch(ops, p, qlim):
+    """mdt_attn_fwd_args.seq_ids / s_cap: a ragged set processed as one launch per length bin (short comments with the
+    small kernels) gives bit-identical out / lse / dQKV — lse rows and dropout counters are those of the sequence's own
+    index, whichever launch computes it."""
+    from multimodaldiscussiontransformer_amd.data.packer import RaggedText
+    nseq, S, H, hd = 37, 104, 3, 64
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(1, S + 1, (nseq,), generator=g, dtype=torch.int32)
+    lens[3], lens[4], lens[5] = S, 64, 65
+    off = torch.zeros(nseq + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(lens, 0)
+    rows = int(off[-1])
+    sl, order = torch.sort(lens.long(), stable=True)
+    rt = RaggedText(rows=rows, max_len=int(lens.max()), offsets=dev(off), ids=None, types=None, pos=None, comment=None,
+                    order=dev(order.to(torch.int32)), sorted_lens=sl.numpy())
+    bins = rt.length_bins(0, caps=(32, 64))
+    assert bins is not None and len(bins) == 3 and sum(int(i.numel()) for i, _ in bins) == nseq
+    for ids, cap in bins:
+        assert int(lens[ids.cpu().long()].max()) <= cap
+    qkv = dev((torch.randn(rows, 3 * H * hd, generator=g) * 0.7).to(torch.bfloat16))
+    dout = dev(torch.randn(rows, H * hd, generator=g).to(torch.bfloat16))
+    kw = dict(drop_p=p, drop_seed=9, seq_offsets=dev(off), q_limit=qlim)
+    o1, l1 = ops.attention_fwd(qkv, nseq, S, H, **kw)
+    d1, _ = ops.attention_bwd(dout, qkv, o1, l1, nseq, S, H, **kw)
+    o2, l2 = ops.attention_fwd(qkv, nseq, S, H, bins=bins, **kw)
+    d2, _ = ops.attention_bwd(dout, qkv, o2, l2, nseq, S, H, bins=bins, **kw)
+    valid = torch.zeros(nseq, H, S, dtype=torch.bool)
+    for s_ in range(nseq):
+        n = int(lens[s_]) if not qlim else min(int(lens[s_]), qlim)
+        valid[s_, :, :n] = True
+    if not qlim:
+        assert torch.equal(o1, o2)
+    assert torch.equal(l1.cpu()[valid], l2.cpu()[valid])
+    # without dropout the single launch takes the whole-row backward (exp instead of exp2 arithmetic): bf16-rounding apart
+    torch.testing.assert_close(d2.float(), d1.float(), atol=8e-3 * float(d1.float().abs().max()), rtol=0)
+    assert ((d1.float() - d2.float()).norm() / d1.float().norm()).item() <= 3e-3
+
+
 # ----------------------------------------------------------------------------- error behaviour of the C ABI
 def test_abi_rejects_bad_arguments_loudly(ops):
     """Every entry point returns a negative status (raised as MdtError with the library's message) instead of
