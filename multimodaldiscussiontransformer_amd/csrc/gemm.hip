@@ -1004,6 +1004,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
     const int steps = ((blockIdx.x >> 3) & 7) * (nhs / 8);
     for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(28);   // ~ one 32-k step each
   }
+  if (p.epilogue & (1 << 26)) {   // diagnostic (MDT_GEMM_DIAG=64): skew whole XCDs against each other (their workgroups stay in phase)
+    const int steps = (blockIdx.x & 7) * ((nhs + 12) / 8);          // a tile period ~ nhs steps + an epilogue worth ~12
+    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(28);
+  }
   // Tile walk.  Static (tile_queue == NULL): v = blockIdx.x, + gridDim.x, ...  Dynamic: the first tile is blockIdx.x,
   // every later one comes from a queue — one head per XCD (virtual ids v = x + 8 j keep the XCD-aware order), other
   // XCDs' queues are raided when the own one is empty — so a CU that starts late or shares its time with another
@@ -1038,6 +1042,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
   wait_pieces(PP_DIST - 1);
   int b_rd = 0, b_wr = PP_DIST % PP_NB;
   unsigned long long t_cyc = 0, t_real = 0, s_cyc = 0, s_real = 0, s_nk = 0, t_first = 0;
+  int tile_no = 0;
 
   for (;;) {
     f32x4 acc[8][4];
@@ -1049,7 +1054,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
     if (late) __builtin_amdgcn_s_barrier();      // the stagger: waves 4-7 run one segment behind
     __builtin_amdgcn_sched_barrier(0);
     if (p.stamps) { t_cyc = __builtin_amdgcn_s_memtime(); t_real = __builtin_amdgcn_s_memrealtime(); if (!t_first) t_first = t_real; }
+    ++tile_no;
+    const bool step_stamp = p.stamps && tid == 0 && blockIdx.x == 9 && (tile_no == 4 || tile_no == 5) && nhs <= 100;
     for (int hs = 0; hs < nhs; ++hs) {
+      if (step_stamp) p.stamps[4 * (size_t)gridDim.x + (tile_no - 4) * (nhs + 2) + hs] = __builtin_amdgcn_s_memtime();
       const char* rd = smem + b_rd * PP_STAGE;
       bf16x8 a[8], b[4];
 #pragma unroll
@@ -1094,6 +1102,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
     }
     if (!late) __builtin_amdgcn_s_barrier();     // both groups leave the tile together
     if (p.stamps) { s_cyc += __builtin_amdgcn_s_memtime() - t_cyc; s_real += __builtin_amdgcn_s_memrealtime() - t_real; s_nk += nhs / 2; }
+    if (step_stamp) p.stamps[4 * (size_t)gridDim.x + (tile_no - 4) * (nhs + 2) + nhs] = __builtin_amdgcn_s_memtime();
     int popped = -1;
     if (dyn && has_next && tid == 0) popped = pop_tile();       // the tile after next; returns while the epilogue runs
     if constexpr (F8 != 0) {
@@ -1103,6 +1112,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
     } else {
       direct_epilogue<2, EPK>(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 64);
     }
+    if (step_stamp) p.stamps[4 * (size_t)gridDim.x + (tile_no - 4) * (nhs + 2) + nhs + 1] = __builtin_amdgcn_s_memtime();
     if (!has_next) break;
     cur = nxt;
     if (dyn) {
@@ -1299,6 +1309,14 @@ static void report_stamps(unsigned long long* dev, size_t nwg, const GemmParams&
   fprintf(stderr, "[mdt gemm stamp] M=%lld N=%lld K=%lld wgs=%zu  cycles/k-tile median %.0f (p10 %.0f p90 %.0f)  clock median %.0f MHz  span %.1f us\n",
           (long long)p.M, (long long)p.N, (long long)p.K, nwg, cyc[cyc.size() / 2], cyc[cyc.size() / 10], cyc[cyc.size() * 9 / 10],
           clk[clk.size() / 2], (double)(t1 - t0) / 100.0);
+  // step stamps of one tile of one workgroup (persistent kernel): shader cycles between consecutive 32-k steps, then
+  // loop end -> epilogue end -> first step of the next tile
+  std::vector<unsigned long long> st(256);
+  if (hipMemcpy(st.data(), dev + nwg * 4, 256 * 8, hipMemcpyDeviceToHost) == hipSuccess && st[0]) {
+    fprintf(stderr, "[mdt gemm steps]");
+    for (int i = 1; i < 256 && st[i]; ++i) fprintf(stderr, " %llu", st[i] - st[i - 1]);
+    fprintf(stderr, "\n");
+  } else (void)hipGetLastError();
 }
 
 static int num_cus() {
@@ -1377,8 +1395,8 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   const bool stamp = sw.gemm_stamp;
   const size_t nwg = (size_t)grid.x * grid.z;
   if (stamp) {
-    if (hipMalloc(&p.stamps, nwg * 32) != hipSuccess) { (void)hipGetLastError(); p.stamps = nullptr; }
-    else (void)hipMemsetAsync(p.stamps, 0, nwg * 32, st);
+    if (hipMalloc(&p.stamps, nwg * 32 + 256 * 8) != hipSuccess) { (void)hipGetLastError(); p.stamps = nullptr; }
+    else (void)hipMemsetAsync(p.stamps, 0, nwg * 32 + 256 * 8, st);
   }
   // prefetch distance in 32-k steps.  In-call A/B at the C2 shapes: 4 (five stages = all of LDS) beats 2 and 3 by
   // 1-3 % per GEMM, 0.6 % on the whole step — the fill is throughput- rather than latency-bound
@@ -1544,7 +1562,7 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   p.tile_queue = nullptr;
   p.alpha_dev = p.alpha_dev2 = nullptr;
   p.group_n = 1 << 30;   // row-major unless launch_pp256 decides otherwise
-  p.epilogue |= switches().gemm_diag << 20;   // diagnostics: 1 skip stores, 2 sc1 stores, 4 skewed starts, 8 every tile loads tile (0,0)'s panels
+  p.epilogue |= switches().gemm_diag << 20;   // diagnostics: 1 skip stores, 2 sc1 stores, 4 skewed starts within an XCD, 8 every tile loads tile (0,0)'s panels, 64 XCDs skewed against each other
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_COLSUM) || (colsum && split_k == 1), "mdt_gemm: MDT_EPI_COLSUM needs a colsum buffer and split_k == 1");
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_ASUM) || (colsum && trans_a && (epilogue & MDT_EPI_ATOMIC) && !(epilogue & MDT_EPI_COLSUM) && dtype == MDT_BF16),
                 "mdt_gemm: MDT_EPI_ASUM needs bf16 operands, trans_a = 1, MDT_EPI_ATOMIC, a colsum buffer and no MDT_EPI_COLSUM");
