@@ -177,3 +177,18 @@ def test_rccl_bucketed_exchange_world1_equals_plain_backward(monkeypatch):
     assert set(plain) == set(forced)
     for n_ in plain:
         torch.testing.assert_close(forced[n_], plain[n_], atol=2e-5 * max(1.0, float(plain[n_].abs().max())), rtol=1e-4, msg=n_)
+
+
+def test_launcher_does_not_train_the_shipped_recipe_from_random_encoders():
+    """run_train.sh builds its encoders with from_pretrained(); without those weights on disk (no network here) the
+    launcher stops with instructions instead of training BERT-base / ViT-B from random init.  --random-init-encoders,
+    --restore-file or a custom --bert-config / --vit-config shape (every other test of this file) say otherwise explicitly."""
+    from multimodaldiscussiontransformer_amd import train
+    argv = ["--task", "node_prediction", "--arch", "multi_graphormer_base", "--criterion", "node_cross_entropy",
+            "--dataset-name", "synthetic", "--max-update", "1", "--num_fusion_layers", "5", "--num_graph_stack", "1",
+            "--num_fusion_stack", "1", "--num_bottleneck_tokens", "4", "--no-save", "--encoder-embed-dim", "768",
+            "--encoder-ffn-embed-dim", "768", "--encoder-attention-heads", "12"]        # run_train.sh:51-54
+    with pytest.raises(SystemExit, match="never downloads"):
+        train.main(argv)
+    with pytest.raises(SystemExit, match="never downloads"):
+        train.main(argv + ["--pretrained-bert", "/nonexistent/bert", "--pretrained-vit", "/nonexistent/vit"])
