@@ -72,6 +72,12 @@ class GraphormerModel(FairseqEncoderModel):
         parser.add_argument("--pre-layernorm", action="store_true",
                             help="apply layernorm before self-attention and ffn. Without this, post layernorm will used")
         parser.add_argument("--freeze_initial_encoders", action="store_true", help="freezes the initial layers ")
+        # not in the reference, which hard-codes the hub names and downloads (multigraphormer_graph_encoder.py:236-245):
+        parser.add_argument("--pretrained-bert", default=None, help="HuggingFace BERT weights for the text stack: local directory / "
+                            "file or a name in the LOCAL HF cache (default bert-base-uncased); never downloaded")
+        parser.add_argument("--pretrained-vit", default=None, help="same for the image stack (default google/vit-base-patch16-224)")
+        parser.add_argument("--random-init-encoders", action="store_true", default=False,
+                            help="build the BERT / ViT stacks from random weights instead")
 
     def max_nodes(self):
         return self.encoder.max_nodes
@@ -83,7 +89,19 @@ class GraphormerModel(FairseqEncoderModel):
             args.max_nodes = getattr(args, "tokens_per_sample", 10000)
         logger.info(args)
         encoder = GraphormerEncoder(args)
-        return cls(args, encoder)
+        model = cls(args, encoder)
+        # A parser that went through add_args (FairSeq's, or train.py's) carries --random-init-encoders: such a run gets the
+        # reference's pretrained encoders unless it opts out or runs custom BERT / ViT shapes; programmatic construction
+        # (tests, bench.py: a bare namespace) never touches the disk.
+        custom = getattr(args, "bert_config", None) is not None or getattr(args, "vit_config", None) is not None
+        if hasattr(args, "random_init_encoders") and not args.random_init_encoders and not custom and \
+                not getattr(args, "_skip_pretrained", False):
+            from .. import hf_weights
+            info = hf_weights.load_pretrained_encoders(encoder.graph_encoder,
+                                                       bert=getattr(args, "pretrained_bert", None) or hf_weights.BERT_NAME,
+                                                       vit=getattr(args, "pretrained_vit", None) or hf_weights.VIT_NAME)
+            logger.info("pretrained encoders: %s", info)
+        return model
 
     def forward(self, batched_data, **kwargs):
         return self.encoder(batched_data, **kwargs)

@@ -88,11 +88,6 @@ def build_parser():
     p.add_argument("--synthetic-seq-len", type=int, default=32)
     p.add_argument("--synthetic-image-frac", type=float, default=0.0)
     p.add_argument("--synthetic-batches", type=int, default=8)
-    p.add_argument("--pretrained-bert", default=None, help="HuggingFace BERT weights for the text stack: a local directory / file "
-                   "or a name in the LOCAL HF cache (default: bert-base-uncased, like the reference); never downloaded")
-    p.add_argument("--pretrained-vit", default=None, help="same for the image stack (default: google/vit-base-patch16-224)")
-    p.add_argument("--random-init-encoders", action="store_true", default=False,
-                   help="train the BERT / ViT stacks from random weights (the reference always starts from pretrained ones)")
     p.add_argument("--bert-config", type=json.loads, default=None, help="JSON overrides of the BERT shape (tests)")
     p.add_argument("--vit-config", type=json.loads, default=None)
     # task flags (mDT/src/tasks/task.py:29-113)
@@ -151,21 +146,16 @@ def main(argv=None):
     task = task_cls.setup_task(cfg)
     ARCH_CONFIG_REGISTRY[args.arch](args)
     assert ARCH_MODEL_REGISTRY[args.arch] in MODEL_REGISTRY
-    model = task.build_model(args)
-    custom_shape = args.bert_config is not None or args.vit_config is not None     # not the published models: nothing to load
-    if not args.restore_file and not args.random_init_encoders and not custom_shape:
-        # the reference's encoders come from from_pretrained() (multigraphormer_graph_encoder.py:236-245): same here,
-        # from local files only — a recipe that silently trained from random weights would not be the reference's recipe
-        from . import hf_weights
-        try:
-            info = hf_weights.load_pretrained_encoders(model.encoder.graph_encoder,
-                                                       bert=args.pretrained_bert or hf_weights.BERT_NAME,
-                                                       vit=args.pretrained_vit or hf_weights.VIT_NAME)
-        except FileNotFoundError as e:
-            raise SystemExit(f"[mdt-train] {e}\n[mdt-train] give --pretrained-bert / --pretrained-vit a local path, start from a "
-                             f"checkpoint (--restore-file), or pass --random-init-encoders to train from random weights")
-        if rank == 0:
-            print(json.dumps(dict(pretrained_encoders=info)), flush=True)
+    # the reference's encoders come from from_pretrained() (multigraphormer_graph_encoder.py:236-245): build_model loads the same
+    # HuggingFace weights from LOCAL files (--pretrained-bert / --pretrained-vit) unless the run starts from a checkpoint,
+    # opts out (--random-init-encoders) or uses custom encoder shapes — a recipe that silently trained from random weights
+    # would not be the reference's recipe
+    args._skip_pretrained = bool(args.restore_file)
+    try:
+        model = task.build_model(args)
+    except FileNotFoundError as e:
+        raise SystemExit(f"[mdt-train] {e}\n[mdt-train] give --pretrained-bert / --pretrained-vit a local path, start from a "
+                         f"checkpoint (--restore-file), or pass --random-init-encoders to train from random weights")
     model = model.cuda()
     half = args.fp16 or args.bf16
     if half:
