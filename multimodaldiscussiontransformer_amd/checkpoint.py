@@ -28,7 +28,6 @@ uses to start fine-tuning from a contrastive pre-training checkpoint.
 from __future__ import annotations
 
 import os
-import time
 from collections import OrderedDict
 from typing import Optional
 

@@ -12,7 +12,7 @@ cache only (``local_files_only=True``); nothing is downloaded and a missing mode
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Tuple
 
 import torch
 

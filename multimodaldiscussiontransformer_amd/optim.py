@@ -6,7 +6,6 @@ from __future__ import annotations
 
 import torch
 
-from . import _lib as L
 from ._lib import check, dt, lib, ptr, stream
 
 
