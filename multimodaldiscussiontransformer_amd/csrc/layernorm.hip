@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int D,
 // requested before the current row is reduced), keeps per-lane partial dgamma / dbeta / column sums in registers,
 // the block combines them through ONE [4 waves][row] LDS buffer used three times (16 KiB at D = 768: the 48 KiB of
 // three buffers held a CU to three workgroups) and issues one float atomic per column.
-template <typename T, int NV, bool TAIL>
+template <typename T, int NV, bool TAIL, bool CS = TAIL>   // TAIL: second (dropped) output and / or column sums; CS: the column sums
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D, const T* __restrict__ dy, int64_t lddy,
                                                             const T* __restrict__ x, int64_t ldx,
                                                             const T* __restrict__ gamma, const float* __restrict__ mean,
@@ -112,14 +112,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
   const int64_t r1 = (r0 + rows_per_wave < rows) ? r0 + rows_per_wave : rows;
-  float pg[NV][VN], pb[NV][VN], pc[NV][VN];
+  float pg[NV][VN], pb[NV][VN], pc[CS ? NV : 1][CS ? VN : 1];
   Vec<T> gv[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * VN;
     if (c < D) gv[i] = *(const Vec<T>*)(gamma + c);
 #pragma unroll
-    for (int j = 0; j < VN; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; pc[i][j] = 0.f; }
+    for (int j = 0; j < VN; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; if constexpr (CS) pc[i][j] = 0.f; }
   }
   Vec<T> xv[NV], gy[NV], av[NV], xn[NV], gn[NV], an[NV];
   float mu = 0.f, rs = 0.f, mu_n = 0.f, rs_n = 0.f;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
             } else {
               v = o.get(j);
             }
-            pc[i][j] += v;
+            if constexpr (CS) pc[i][j] += v;
           }
         }
         *(Vec<T>*)(dx + row * lddx + c) = o;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
   const int W = NV * 64 * VN;
   // three rounds through the one buffer: dgamma, dbeta, column sums
 #pragma unroll
-  for (int round = 0; round < (TAIL ? 3 : 2); ++round) {
+  for (int round = 0; round < (CS ? 3 : 2); ++round) {
     float* dst = round == 0 ? dgamma : round == 1 ? dbeta : colsum;
     if (round) __syncthreads();           // the previous round's readers are done
 #pragma unroll
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
 #pragma unroll
       for (int j = 0; j < VN; ++j) {
         const int c = (i * 64 + lane) * VN + j;
-        red[wave * W + c] = round == 0 ? pg[i][j] : round == 1 ? pb[i][j] : pc[i][j];
+        red[wave * W + c] = round == 0 ? pg[i][j] : round == 1 ? pb[i][j] : pc[CS ? i : 0][CS ? j : 0];
       }
     __syncthreads();
     if (dst)
@@ -257,7 +257,11 @@ static int ln_bwd_dispatch(hipStream_t st, int64_t rows, int D, const void* dy, 
   const unsigned grid = (unsigned)((rows + 4 * rpw - 1) / (4 * rpw));
   const bool tail = dxd != nullptr || colsum != nullptr;
 #define LN_BWD(NV_)                                                                                              \
-  if (tail)                                                                                                      \
+  if (tail && !colsum)                                                                                           \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV_, true, false>), grid, 256, (size_t)(4 * NV_ * 64 * VN * 4), st, rows, D, \
+                       (const T*)dy, lddy, (const T*)x, ldx, (const T*)gamma, mean, rstd, (const T*)add, ldadd,  \
+                       (T*)dx, lddx, dgamma, dbeta, rpw, (T*)dxd, lddxd, drop, colsum);                          \
+  else if (tail)                                                                                                 \
     hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV_, true>), grid, 256, (size_t)(4 * NV_ * 64 * VN * 4), st, rows, D, \
                        (const T*)dy, lddy, (const T*)x, ldx, (const T*)gamma, mean, rstd, (const T*)add, ldadd,  \
                        (T*)dx, lddx, dgamma, dbeta, rpw, (T*)dxd, lddxd, drop, colsum);                          \

@@ -281,6 +281,15 @@ def wgrad(tape: Tape, dy: torch.Tensor, x: torch.Tensor, w: torch.nn.Parameter, 
         ops.colsum(dy, out=gb.view(-1))
 
 
+_LN_BIAS_RIDE = os.environ.get("MDT_LN_BIAS_RIDE", "1") != "0"    # 0: those sums stay in the LayerNorm backward (A/B runs)
+
+
+def dyd_rides(g: torch.Tensor) -> bool:
+    """bias gradients of the dense layers behind a LayerNorm ride on their weight-gradient GEMM (MDT_EPI_ASUM) when that
+    GEMM takes the 256 x 256 kernel (bf16, enough rows); small problems keep the sums inside the LayerNorm backward"""
+    return _LN_BIAS_RIDE and g.dtype == torch.bfloat16 and g.shape[0] >= 8192
+
+
 def _ln_bwd(tape, dy, x, w, b, mean, rstd, add=None):
     return ops.layernorm_bwd(dy, x, w.data, mean, rstd, add=add, dgamma=tape.pgrad(w), dbeta=tape.pgrad(b))
 
@@ -391,8 +400,9 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         o.grad = None
         if g is None:
             return
-        dy, dyd = _ln_bwd_dense(tape, g, y, P.ln2_w, P.ln2_b, m2, r2, P.fc2_b, p_hidden, s_f2)
-        wgrad(tape, dyd, h, P.fc2_w, None)
+        ride = _WGRAD_ASUM and dyd_rides(g)     # bias gradients ride on the weight-gradient GEMMs (wgrad) where they can
+        dy, dyd = _ln_bwd_dense(tape, g, y, P.ln2_w, P.ln2_b, m2, r2, None if ride else P.fc2_b, p_hidden, s_f2)
+        wgrad(tape, dyd, h, P.fc2_w, P.fc2_b if ride else None)
         gb1 = tape.pgrad(P.fc1_b)           # fc1 bias gradient = colsum(du): fused into the GEMM epilogue
         du = lin8(dyd, P.fc2_w, "d_fc2", transposed_weight=True, grad=True, aux=u, epilogue=ops.EPI_MULAUX,
                   colsum=None if gb1 is None else gb1.view(-1))
@@ -401,8 +411,8 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
                           colsum=None if gb1 is None else gb1.view(-1))
         wgrad(tape, du, a, P.fc1_w, None)
         da = ops.gemm(du, P.fc1_w.data, trans_b=True, residual=dy)
-        dt_, dtd = _ln_bwd_dense(tape, da, t, P.ln1_w, P.ln1_b, m1, r1, P.o_b, p_hidden, s_o)
-        wgrad(tape, dtd, ctx, P.o_w, None)
+        dt_, dtd = _ln_bwd_dense(tape, da, t, P.ln1_w, P.ln1_b, m1, r1, None if ride else P.o_b, p_hidden, s_o)
+        wgrad(tape, dtd, ctx, P.o_w, P.o_b if ride else None)
         dctx = ops.gemm(dtd, P.o_w.data, trans_b=True)
         dqkv = attn_bwd(dctx)
         wgrad(tape, dqkv, xd, P.qkv_w, P.qkv_b)
@@ -426,8 +436,9 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
                           colsum=None if gb1 is None else gb1.view(-1))
         wgrad(tape, du, n2, P.fc1_w, None)
         dn2 = ops.gemm(du, P.fc1_w.data, trans_b=True)
-        dh, dhd = _ln_bwd_dense(tape, dn2, hmid, P.ln2_w, P.ln2_b, m2, r2, P.o_b, p_hidden, s_o, add=g)
-        wgrad(tape, dhd, ctx, P.o_w, None)
+        ride = _WGRAD_ASUM and dyd_rides(g)
+        dh, dhd = _ln_bwd_dense(tape, dn2, hmid, P.ln2_w, P.ln2_b, m2, r2, None if ride else P.o_b, p_hidden, s_o, add=g)
+        wgrad(tape, dhd, ctx, P.o_w, P.o_b if ride else None)
         dctx = ops.gemm(dhd, P.o_w.data, trans_b=True)
         dqkv = attn_bwd(dctx)
         wgrad(tape, dqkv, n1, P.qkv_w, P.qkv_b)
