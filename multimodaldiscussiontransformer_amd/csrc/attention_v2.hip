@@ -955,6 +955,10 @@ static int launch_v3(hipStream_t st, const AttnParams& p) {
       }
       const int n_t = (cap + 15) / 16;
       const int waves = n_t <= 4 ? 4 : n_t <= 8 ? 8 : 16;
+      if (rows_img * 8 > 2 * waves * 64) {      // the kernel restages K with at most two 16-byte chunks per thread
+        set_error("attention_bwd_v4: %d image rows for %d waves", rows_img, waves);
+        return MDT_ERR_UNSUPPORTED;
+      }
       hipLaunchKernelGGL(k4, dim3(p.f.H, p.f.nseq), waves * 64, lds4, st, p, rows_img, ldq);
       return check_launch("attention_bwd_v4");
     }
