@@ -122,6 +122,38 @@ def test_gemm_wgrad_with_bias_gradient_riding(ops, rows, N, K, split):
     torch.testing.assert_close(gb.cpu(), ref_b, atol=2e-3 * (rows ** 0.5), rtol=1e-4)
 
 
+@pytest.mark.parametrize("tb,kind", [(False, "bias"), (False, "dense"), (True, "plain"), (True, "res")])
+def test_gemm_four_wave_form_is_bit_identical(ops, tb, kind, monkeypatch):
+    """MDT_GEMM_W4=1: the experimental 4-wave persistent kernel (gemm_bf16_w4p: one wave per SIMD, 128 x 128 per wave,
+    hand-ordered MFMA / fragment-read / LDS-DMA stream) accumulates every element in the same k order through the same
+    epilogue code as the 8-wave kernel: identical bits, ragged last row tile included."""
+    from multimodaldiscussiontransformer_amd import _lib as L
+    M, N, K = 66000 + 37, 768, 768
+    bf = torch.bfloat16
+    a = dev(rnd(M, K, seed=31).to(bf))
+    b = dev((rnd(K, N, seed=32) if tb else rnd(N, K, seed=32)).to(bf))
+    kw = dict(trans_b=tb)
+    if kind in ("bias", "dense"):
+        kw["bias"] = dev(rnd(N, seed=33).to(bf))
+    if kind in ("dense", "res"):
+        kw["residual"] = dev(rnd(M, N, seed=34).to(bf))
+    if kind == "dense":
+        kw.update(drop_p=0.4, drop_seed=7)
+    outs = []
+    try:
+        for v in ("0", "1"):
+            monkeypatch.setenv("MDT_GEMM_W4", v)
+            L.reload_env()
+            outs.append(ops.gemm(a, b, **kw).clone())
+    finally:
+        monkeypatch.delenv("MDT_GEMM_W4")
+        L.reload_env()
+    assert torch.equal(outs[0], outs[1])
+    ref = a.float() @ (b.float() if tb else b.float().t())
+    if kind == "plain":
+        torch.testing.assert_close(outs[1].float(), ref, atol=0.5, rtol=2e-2)
+
+
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_gemm_bf16_tile256_pipeline(ops, ta, tb):
     """Shapes large enough for the 256x128 three-stage kernel (>= 256 tiles), ragged M tail,

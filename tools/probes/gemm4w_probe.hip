@@ -24,7 +24,8 @@ __device__ __forceinline__ int swz_h(int row) { return (0x78 >> (2 * ((row >> 2)
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// VARIANT 0: loads first, then MFMAs, compiler's own interleaving; 1: sched_group_barrier pattern (2 MFMA : 1 ds_read, then 4 MFMA : 1 DMA)
+// VARIANT 0: loads first, then MFMAs, compiler's own interleaving; 1: sched_group_barrier pattern (2 MFMA : 1 ds_read, then 4 MFMA : 1 DMA);
+// 2: source order = issue order (MFMAs as volatile asm with memory clobbers)
 template <int VARIANT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void loop_probe(const __bf16* A, const __bf16* B, int K, int tiles,
                                                                                             unsigned long long* cycles, float* sink) {
@@ -79,6 +80,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     wait_vm<(DIST - 2) * 8>();                    // own pieces of step s + 1 have landed (s + 2, s + 3 may be in flight)
     __builtin_amdgcn_s_barrier();                 // ... and everybody's; stage s - 1 is free to be overwritten
     const char* tn = smem + b_next * STAGE;
+    if constexpr (VARIANT == 2) {
+      // source order IS the issue order: every MFMA is a volatile asm statement with a memory clobber, so the fragment
+      // reads and the LDS-DMA issues stay where they are written — 2 MFMAs, a read, 2 MFMAs, a read, 2 MFMAs, a DMA, 2 MFMAs
+      char* st = smem + b_wr * STAGE;
+      const int ko = ((s + DIST) % nhs) * 64;
+#define MF(i_, j_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i_][j_]) : "v"(fb[cur][j_]), "v"(fa[cur][i_]) : "memory")
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        MF(b, 0); MF(b, 1);
+        fa[nxt][b] = frag(tn, wr * 128 + b * 16);
+        MF(b, 2); MF(b, 3);
+        fb[nxt][b] = frag(tn + 256 * 64, wc * 128 + b * 16);
+        MF(b, 4); MF(b, 5);
+        if (b < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(st + (wave + 4 * b) * 1024), 16, voff[b], ko, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(st + 256 * 64 + (wave + 4 * (b - 4)) * 1024), 16, voff[b - 4], ko, 0, 0);
+        MF(b, 6); MF(b, 7);
+      }
+#undef MF
+    } else {
 #pragma unroll
     for (int i = 0; i < 8; ++i) { fa[nxt][i] = frag(tn, wr * 128 + i * 16); fb[nxt][i] = frag(tn + 256 * 64, wc * 128 + i * 16); }
     issue((s + DIST) % nhs, b_wr);
@@ -86,6 +106,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
+    }
     if constexpr (VARIANT == 1) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
@@ -147,6 +168,7 @@ int main() {
   for (int k : {768, 3072}) {
     run<0>("4 waves, compiler's interleaving", A, B, k, 64 * 3072 / k, dcyc, sink);
     run<1>("4 waves, sched_group_barrier pattern", A, B, k, 64 * 3072 / k, dcyc, sink);
+    run<2>("4 waves, hand-ordered (asm MFMAs)", A, B, k, 64 * 3072 / k, dcyc, sink);
   }
   return 0;
 }
