@@ -194,6 +194,8 @@ def load_checkpoint(path: str, model, *, optimizer=None, reset_optimizer: bool =
         out["extra_state"] = extra
     if not reset_dataloader:
         out["epoch"] = int((extra.get("train_iterator") or {}).get("epoch", 1))
+    from . import engine
+    engine.weights_changed()          # cached transposed weight copies (engine.dgrad) are stale
     return out
 
 

@@ -48,7 +48,7 @@ struct Switches {
   int gemm_diag;             // MDT_GEMM_DIAG      (0: none)
   char gemm_tile[16];        // MDT_GEMM_TILE      ("" unset)
   bool gemm_no_pp;           // MDT_GEMM_NO_PP
-  int gemm_w4;               // MDT_GEMM_W4        (0: off; 1: the 4-wave persistent kernel for every persistent launch; n > 1: for K <= n)
+  int gemm_w4;               // MDT_GEMM_W4        (default 2: the 4-wave persistent kernel where it is measured faster; 0: never; 1: every persistent launch)
   bool attn_v1;              // MDT_ATTN_V1
   char attn_bwd[8];          // MDT_ATTN_BWD       ("" unset)
   bool attn_no_occ4;         // MDT_ATTN_NO_OCC4

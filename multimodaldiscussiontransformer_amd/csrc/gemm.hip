@@ -392,8 +392,11 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
 // follows it with s_waitcnt vmcnt(0), which on this in-order counter also waits for the store of the row group
 // before: 16 serialised memory round trips per tile (0.53-0.90 PFLOP/s in situ on the residual / saved-derivative
 // GEMMs against 1.05-1.13 on the same shapes without).
-template <int NJP, int EPK = -1>   // NJP pairs of 16-column tiles per wave: 2 (128x64 blocks) or 4 (128x128 blocks)
-__device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc)[8][2 * NJP], int lane, int64_t m0w, int64_t n0w) {
+// PEND: the outputs of row tiles 4-7 are not stored but handed back packed (pend[(i - 4) * NJP + jp], 16 bytes per lane each):
+// the 4-wave kernel keeps them in registers and lets them leave during the next tile's first steps.
+template <int NJP, int EPK = -1, bool PEND = false>   // NJP pairs of 16-column tiles per wave: 2 (128x64 blocks) or 4 (128x128 blocks)
+__device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc)[8][2 * NJP], int lane, int64_t m0w, int64_t n0w,
+                                                bf16x8* pend = nullptr) {
   const int c = lane & 15, g = lane >> 4;
   const int ep = EPK >= 0 ? EPK : p.epilogue;
   constexpr int PRE_KIND = EPK < 0 ? 0 : (EPK & (MDT_EPI_MULAUX | MDT_EPI_DGELU)) ? 1 : (EPK & MDT_EPI_RESIDUAL) ? 2 : (EPK & MDT_EPI_ACCUM) ? 3 : 0;
@@ -447,7 +450,10 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
         v[r] = lo;
         v[4 + r] = hi;
       }
-      if (!live) break;
+      if (!live) {
+        if constexpr (PEND && i >= 4) pend[(i - 4) * NJP + jp] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};   // the store drops rows past M
+        break;
+      }
       const int64_t gc = gcs[jp];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], p.alpha, bias[jp][e]);
@@ -518,6 +524,7 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+      if constexpr (PEND && i >= 4) { pend[(i - 4) * NJP + jp] = o; break; }
       if (ep & (1 << 20)) break;                          // diagnostic: no output store
       if (ep & (1 << 21)) {                               // diagnostic: write-through, do not keep the line in L2
         const i32x4 raw = __builtin_bit_cast(i32x4, o);
@@ -1270,7 +1277,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   int b_next = 1, b_wr = PP_DIST % PP_NB;
   f32x4 acc[8][8];
 
-  // one 32-k step on fragment set `cur`: FIRST starts the accumulators from zero
+  // Pending outputs: row tiles 4-7 of a finished tile stay packed in registers (16 vectors of 16 bytes per lane) and
+  // leave two per step during steps 0-7 of the next tile, through a buffer descriptor based at the tile's origin (rows past
+  // M fall outside it and are dropped).  The other half is stored at the tile's end as before: the burst is half as long.
+  constexpr bool PEND = EPK >= 0;                  // the specialised epilogues (the runtime-flag kernel keeps the plain form)
+  bf16x8 pend[16];
+  __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, 0, 0x00020000);
+  const int c_lane = lane & 15, g_lane = lane >> 4;
+  const unsigned voffP = (unsigned)((wr * 128 + c_lane) * (p.ldc * 2) + (wc * 128 + 16 * (g_lane & 1) + 8 * (g_lane >> 1)) * 2);
+  const int ldc16 = (int)(p.ldc * 2 * 16);         // bytes between row tiles
+  auto desc_c = [&](const Desc& d) {
+    const int64_t bytes = (p.M - d.m0) * p.ldc * 2 - d.n0 * 2;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((bf16_t*)p.C + d.m0 * p.ldc + d.n0), 0,
+                                             (unsigned)(bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : bytes), 0x00020000);
+  };
+
+  // one 32-k step on fragment set `cur`: FIRST starts the accumulators from zero; NW = vector-memory operations that may
+  // still be in flight when the step begins; ST >= 0: pending vectors ST and ST + 1 leave in this step
   // (the host pass of hipcc parses kernel bodies too and knows no "a" / "v" register classes: it gets an empty statement)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define W4_MF(i_, j_)                                                                                             \
@@ -1279,21 +1302,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
 #define W4_MF(i_, j_) (void)first
 #endif
-  auto step = [&](auto cs_c, auto first_c, const Desc& d_issue, int hs_issue) __attribute__((always_inline)) {
+  auto step = [&](auto cs_c, auto first_c, auto nw_c, auto st_c, auto ld_c, const Desc& d_issue, int hs_issue) __attribute__((always_inline)) {
     constexpr int cs = decltype(cs_c)::value, ns = cs ^ 1;
     constexpr bool first = decltype(first_c)::value;
+    constexpr int NW = decltype(nw_c)::value, ST = decltype(st_c)::value;
+    constexpr bool LD = decltype(ld_c)::value;       // false in a tile's last step: the next tile's first fragments are read after the epilogue
     const int sa = soff_a(d_issue, hs_issue), sb = soff_b(d_issue, hs_issue);
-    wait_vm<(PP_DIST - 2) * 8>();                 // own pieces of the next step have landed (two later steps may be in flight)
+    wait_vm<NW>();                                // own pieces of the next step have landed
     __builtin_amdgcn_s_barrier();                 // ... and everybody's; the stage of the previous step is free
     const char* tn = smem + b_next * PP_STAGE;
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
       W4_MF(b, 0); W4_MF(b, 1);
-      fa[ns][b] = load_frag_h<A_KM, BM>(tn, wr * 128 + b * 16, lane);
+      if constexpr (LD) fa[ns][b] = load_frag_h<A_KM, BM>(tn, wr * 128 + b * 16, lane);
       W4_MF(b, 2); W4_MF(b, 3);
-      fb[ns][b] = load_frag_h<B_KM, BN>(tn + A_BYTES, wc * 128 + b * 16, lane);
+      if constexpr (LD) fb[ns][b] = load_frag_h<B_KM, BN>(tn + A_BYTES, wc * 128 + b * 16, lane);
       W4_MF(b, 4); W4_MF(b, 5);
       issue_piece(d_issue, sa, sb, b_wr, b);
+      if constexpr (ST >= 0) {
+        if (b == 2 || b == 6) {
+          constexpr int dummy = 0; (void)dummy;
+          const int idx = ST + (b == 6 ? 1 : 0);       // pending vector -> row tile 4 + idx / 4, column pair idx % 4
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, pend[ST + (b == 6 ? 1 : 0)]), rsP, voffP,
+                                                 (4 + (idx >> 2)) * ldc16 + (idx & 3) * 64, 0);
+        }
+      }
       W4_MF(b, 6); W4_MF(b, 7);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1305,22 +1338,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   using T_ = std::true_type;
   using F_ = std::false_type;
   // which stage a step requests: the same tile's step hs + 4, or — in the last four steps — the next tile's first steps
-  auto run_step = [&](auto cs_c, auto first_c, int hs) __attribute__((always_inline)) {
+  auto run_step = [&](auto cs_c, auto first_c, auto nw_c, auto st_c, auto ld_c, int hs) __attribute__((always_inline)) {
     const int tgt = hs + PP_DIST;
     const bool same = tgt < nhs;
     Desc d = nxt;
     if (same) d = cur;
-    step(cs_c, first_c, d, same ? tgt : tgt - nhs);
+    step(cs_c, first_c, nw_c, st_c, ld_c, d, same ? tgt : tgt - nhs);
   };
+#define W4_N(n_) std::integral_constant<int, n_> {}
+  bool have_pend = false;
   for (;;) {
-    // K is a multiple of 64: a tile has an even number of 32-k steps, so every tile starts on fragment set 0
-    run_step(C0{}, T_{}, 0);
-    run_step(C1{}, F_{}, 1);
-    for (int hs = 2; hs < nhs; hs += 2) {
-      run_step(C0{}, F_{}, hs);
-      run_step(C1{}, F_{}, hs + 1);
+    // K is a multiple of 64: a tile has an even number of 32-k steps, so every tile starts on fragment set 0.
+    // vmcnt budgets: a step issues 8 pieces, and 2 stores while pending vectors leave (steps 0-7 after a tile of this
+    // workgroup): pieces of the next step were requested three steps ago, so what may be in flight is what the two steps in
+    // between issued — 16, 18 or 20 operations.
+    if (PEND && have_pend) {
+      run_step(C0{}, T_{}, W4_N(16), W4_N(0), T_{}, 0);
+      run_step(C1{}, F_{}, W4_N(18), W4_N(2), T_{}, 1);
+      run_step(C0{}, F_{}, W4_N(20), W4_N(4), T_{}, 2);
+      run_step(C1{}, F_{}, W4_N(20), W4_N(6), T_{}, 3);
+      run_step(C0{}, F_{}, W4_N(20), W4_N(8), T_{}, 4);
+      run_step(C1{}, F_{}, W4_N(20), W4_N(10), T_{}, 5);
+      run_step(C0{}, F_{}, W4_N(20), W4_N(12), T_{}, 6);
+      run_step(C1{}, F_{}, W4_N(20), W4_N(14), T_{}, 7);
+      run_step(C0{}, F_{}, W4_N(20), W4_N(-1), T_{}, 8);
+      run_step(C1{}, F_{}, W4_N(18), W4_N(-1), T_{}, 9);
+    } else {
+      run_step(C0{}, T_{}, W4_N(16), W4_N(-1), T_{}, 0);
+      run_step(C1{}, F_{}, W4_N(16), W4_N(-1), T_{}, 1);
+      for (int hs = 2; hs < 10; hs += 2) {
+        run_step(C0{}, F_{}, W4_N(16), W4_N(-1), T_{}, hs);
+        run_step(C1{}, F_{}, W4_N(16), W4_N(-1), T_{}, hs + 1);
+      }
     }
-    direct_epilogue<4, EPK>(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 128);
+    for (int hs = 10; hs < nhs - 2; hs += 2) {    // host: nhs >= 12
+      run_step(C0{}, F_{}, W4_N(16), W4_N(-1), T_{}, hs);
+      run_step(C1{}, F_{}, W4_N(16), W4_N(-1), T_{}, hs + 1);
+    }
+    run_step(C0{}, F_{}, W4_N(16), W4_N(-1), T_{}, nhs - 2);
+    const int b_prime = b_next;                   // the stage holding the next tile's first step
+    run_step(C1{}, F_{}, W4_N(16), W4_N(-1), F_{}, nhs - 1);
+    direct_epilogue<4, EPK, PEND>(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 128, pend);
+    {                                             // fragments of the next tile's first step (its stage landed a step ago)
+      const char* t0 = smem + b_prime * PP_STAGE;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        fa[0][i] = load_frag_h<A_KM, BM>(t0, wr * 128 + i * 16, lane);
+        fb[0][i] = load_frag_h<B_KM, BN>(t0 + A_BYTES, wc * 128 + i * 16, lane);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if constexpr (PEND) {
+      if (has_next) { rsP = desc_c(cur); have_pend = true; }
+      else {                                      // nothing follows: the pending half leaves now
+        const __amdgpu_buffer_rsrc_t rl = desc_c(cur);
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, pend[idx]), rl, voffP, (4 + (idx >> 2)) * ldc16 + (idx & 3) * 64, 0);
+      }
+    }
     if (!has_next) break;
     cur = nxt;
     v += gridDim.x;
@@ -1328,6 +1404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     has_next = v_next >= 0;
     nxt = has_next ? make_desc(v_next) : null_desc(cur);
   }
+#undef W4_N
 #undef W4_MF
 }
 
@@ -1537,9 +1614,13 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   const bool persist = persist_ok && sizeof(TOut) == 2 && p.split_k == 1 && nhs_total >= 4 && (int)grid.x > num_cus();
   if (persist) grid.x = (unsigned)num_cus();
   p.tile_queue = nullptr;
-  if (persist && nhs_total >= 8) {
-    const int w4 = sw.gemm_w4;                   // MDT_GEMM_W4: 0 off, 1 every persistent launch, n > 1: launches with K <= n
-    const bool use_w4 = w4 == 1 || (w4 > 1 && p.K <= w4);
+  if (persist && nhs_total >= 12) {
+    // MDT_GEMM_W4: 0 off; 1 every persistent launch; 2 the launches it is measured faster on (k-contiguous operands, light
+    // epilogues: plain, bias, residual, bias + dropout + residual — not the GELU form, not k-major operands)
+    const int w4 = sw.gemm_w4;
+    const int e_ = p.epilogue;
+    const bool light = e_ == 0 || e_ == MDT_EPI_BIAS || e_ == MDT_EPI_RESIDUAL || e_ == (MDT_EPI_BIAS | MDT_EPI_RESIDUAL | MDT_EPI_DROPOUT);
+    const bool use_w4 = (w4 == 1 || (w4 == 2 && !ta && !tb && light && !sw.gemm_no_spec)) && !(sw.gemm_dynamic && g_tile_queues);
     if (use_w4) {
       p.group_n = p.tiles_n;
       {
@@ -1570,6 +1651,9 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
         if (e == E_BIAS) LW4(false, false, E_BIAS)
         else if (e == E_DENSE) LW4(false, false, E_DENSE)
         else if (e == E_FC1 && p.aux) LW4(false, false, E_FC1)
+        else if (e == 0) LW4(false, false, 0)
+        else if (e == E_RES) LW4(false, false, E_RES)
+        else if (e == E_DFC2) LW4(false, false, E_DFC2)
         else LW4(false, false, -1)
       } else if (!ta && tb) {
         if (e == 0) LW4(false, true, 0)
@@ -1661,6 +1745,9 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
       if (e == E_BIAS) LPS(false, false, E_BIAS)
       else if (e == E_DENSE) LPS(false, false, E_DENSE)
       else if (e == E_FC1 && p.aux) LPS(false, false, E_FC1)
+      else if (e == 0) LPS(false, false, 0)                 // input gradients against a transposed weight copy
+      else if (e == E_RES) LPS(false, false, E_RES)
+      else if (e == E_DFC2) LPS(false, false, E_DFC2)
       else LPS(false, false, -1)
     } else if (!ta && tb) {
       if (e == 0) LPS(false, true, 0)

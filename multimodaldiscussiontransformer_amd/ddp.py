@@ -285,6 +285,8 @@ class DataParallel:
                     b.copy_(flat[off:off + b.numel()].view(b.shape))
                     off += b.numel()
                 batch, size = ([t], t.numel() * t.element_size()) if t is not None else ([], 0)
+        from . import engine
+        engine.weights_changed()          # written through .data: cached transposed copies (engine.dgrad) are stale
 
     def diagnostics(self) -> dict:
         """What the first multi-GPU run should print about itself (bench.py puts it into its JSON line)."""

@@ -20,6 +20,7 @@ import os
 
 import contextlib
 import threading
+import weakref
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
 
@@ -284,6 +285,42 @@ def wgrad(tape: Tape, dy: torch.Tensor, x: torch.Tensor, w: torch.nn.Parameter, 
 _LN_BIAS_RIDE = os.environ.get("MDT_LN_BIAS_RIDE", "1") != "0"    # 0: those sums stay in the LayerNorm backward (A/B runs)
 
 
+# ------------------------------------------------------------------------------------------
+# input gradients against a transposed weight copy
+_NN_DGRAD = os.environ.get("MDT_NN_DGRAD", "1") != "0"     # 0: dX = dY W always reads W in place (k-major operand) — A/B runs
+_WT_CACHE: dict = {}
+WEIGHT_EPOCH = 0            # bumped by whoever rewrites weights behind torch's back (optim.FusedAdam.step)
+
+
+def weights_changed():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def _transposed(w: torch.nn.Parameter) -> torch.Tensor:
+    """W^T ([in, out], contiguous) of a Linear weight [out, in], cached until the weight changes (torch-side writes bump
+    ``_version``, the fused optimiser bumps WEIGHT_EPOCH)."""
+    key = id(w)
+    ver = (w._version, WEIGHT_EPOCH, w.data_ptr())
+    hit = _WT_CACHE.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == ver:
+        return hit[2]
+    wt = ops.transpose2d(w.data)
+    _WT_CACHE[key] = (weakref.ref(w), ver, wt)
+    return wt
+
+
+def dgrad(dy: torch.Tensor, w: torch.nn.Parameter, **kw) -> torch.Tensor:
+    """dX[M, in] = dY[M, out] @ W[out, in] (+ epilogue).  For the big launches the weight is read through a transposed
+    bf16 copy, so that both operands are k-contiguous: the k-major form costs the GEMM 4-8 % (two ds_read_b64_tr_b16 per
+    fragment) and the 4-wave kernel takes k-contiguous operands only; the copies (2 bytes per block parameter, one
+    transpose per optimiser step) are negligible beside that.  Small problems and the o projection (768 x 768) read W in
+    place."""
+    if _NN_DGRAD and dy.dtype == torch.bfloat16 and dy.shape[0] >= 8192 and w.shape[0] * w.shape[1] >= 1_500_000:
+        return ops.gemm(dy, _transposed(w), **kw)
+    return ops.gemm(dy, w.data, trans_b=True, **kw)
+
+
 def dyd_rides(g: torch.Tensor) -> bool:
     """bias gradients of the dense layers behind a LayerNorm ride on their weight-gradient GEMM (MDT_EPI_ASUM) when that
     GEMM takes the 256 x 256 kernel (bf16, enough rows); small problems keep the sums inside the LayerNorm backward"""
@@ -407,17 +444,17 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         du = lin8(dyd, P.fc2_w, "d_fc2", transposed_weight=True, grad=True, aux=u, epilogue=ops.EPI_MULAUX,
                   colsum=None if gb1 is None else gb1.view(-1))
         if du is None:
-            du = ops.gemm(dyd, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_MULAUX,
+            du = dgrad(dyd, P.fc2_w, aux=u, epilogue=ops.EPI_MULAUX,
                           colsum=None if gb1 is None else gb1.view(-1))
         wgrad(tape, du, a, P.fc1_w, None)
-        da = ops.gemm(du, P.fc1_w.data, trans_b=True, residual=dy)
+        da = dgrad(du, P.fc1_w, residual=dy)
         dt_, dtd = _ln_bwd_dense(tape, da, t, P.ln1_w, P.ln1_b, m1, r1, None if ride else P.o_b, p_hidden, s_o)
         wgrad(tape, dtd, ctx, P.o_w, P.o_b if ride else None)
         dctx = ops.gemm(dtd, P.o_w.data, trans_b=True)
         dqkv = attn_bwd(dctx)
         wgrad(tape, dqkv, xd, P.qkv_w, P.qkv_b)
         if x.needs_grad:
-            tape.add_grad(x, ops.gemm(dqkv, P.qkv_w.data, trans_b=True, residual=spread(dt_, xd.shape[0])))
+            tape.add_grad(x, dgrad(dqkv, P.qkv_w, residual=spread(dt_, xd.shape[0])))
         if tape.on_params_ready:
             tape.on_params_ready(P.all())
 
@@ -432,10 +469,10 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         du = lin8(gd, P.fc2_w, "d_fc2", transposed_weight=True, grad=True, aux=u, epilogue=ops.EPI_MULAUX,
                   colsum=None if gb1 is None else gb1.view(-1))
         if du is None:
-            du = ops.gemm(gd, P.fc2_w.data, trans_b=True, aux=u, epilogue=ops.EPI_MULAUX,
+            du = dgrad(gd, P.fc2_w, aux=u, epilogue=ops.EPI_MULAUX,
                           colsum=None if gb1 is None else gb1.view(-1))
         wgrad(tape, du, n2, P.fc1_w, None)
-        dn2 = ops.gemm(du, P.fc1_w.data, trans_b=True)
+        dn2 = dgrad(du, P.fc1_w)
         ride = _WGRAD_ASUM and dyd_rides(g)
         dh, dhd = _ln_bwd_dense(tape, dn2, hmid, P.ln2_w, P.ln2_b, m2, r2, None if ride else P.o_b, p_hidden, s_o, add=g)
         wgrad(tape, dhd, ctx, P.o_w, P.o_b if ride else None)
@@ -443,10 +480,10 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         dqkv = attn_bwd(dctx)
         wgrad(tape, dqkv, n1, P.qkv_w, P.qkv_b)
         if x.needs_grad:
-            dn1 = ops.gemm(dqkv, P.qkv_w.data, trans_b=True)
+            dn1 = dgrad(dqkv, P.qkv_w)
             tape.add_grad(x, _ln_bwd(tape, dn1, xd, P.ln1_w, P.ln1_b, m1, r1, add=spread(dh, xd.shape[0])))
         else:   # LayerNorm parameters still need their gradients
-            dn1 = ops.gemm(dqkv, P.qkv_w.data, trans_b=True)
+            dn1 = dgrad(dqkv, P.qkv_w)
             _ln_bwd(tape, dn1, xd, P.ln1_w, P.ln1_b, m1, r1)
         if tape.on_params_ready:
             tape.on_params_ready(P.all())

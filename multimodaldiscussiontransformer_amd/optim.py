@@ -71,6 +71,8 @@ class FusedAdam:
         from . import fp8
         if fp8.ACTIVE is not None:
             fp8.ACTIVE.optimizer_stepped()      # the cached 8-bit weight copies are stale now
+        from . import engine
+        engine.weights_changed()                # ... and the transposed copies the input gradients read
 
     def _step_rest(self, lr, grad_scale, done):
         for p in self.params:

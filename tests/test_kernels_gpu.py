@@ -124,9 +124,10 @@ def test_gemm_wgrad_with_bias_gradient_riding(ops, rows, N, K, split):
 
 @pytest.mark.parametrize("tb,kind", [(False, "bias"), (False, "dense"), (True, "plain"), (True, "res")])
 def test_gemm_four_wave_form_is_bit_identical(ops, tb, kind, monkeypatch):
-    """MDT_GEMM_W4=1: the experimental 4-wave persistent kernel (gemm_bf16_w4p: one wave per SIMD, 128 x 128 per wave,
-    hand-ordered MFMA / fragment-read / LDS-DMA stream) accumulates every element in the same k order through the same
-    epilogue code as the 8-wave kernel: identical bits, ragged last row tile included."""
+    """MDT_GEMM_W4: the 4-wave persistent kernel (gemm_bf16_w4p: one wave per SIMD, 128 x 128 per wave, hand-ordered
+    MFMA / fragment-read / LDS-DMA stream, half of a finished tile leaving during the next tile's first steps) accumulates
+    every element in the same k order through the same epilogue code as the 8-wave kernel (MDT_GEMM_W4=0): identical
+    bits, ragged last row tile included.  =1 forces it on every persistent launch (k-major operands too)."""
     from multimodaldiscussiontransformer_amd import _lib as L
     M, N, K = 66000 + 37, 768, 768
     bf = torch.bfloat16

@@ -62,6 +62,14 @@ def combos(M):
         out.append(("NN bias+res+drop", x768, w, dict(bias=r(768), residual=r(M, 768), drop_p=0.4, drop_seed=3)))
         out.append(("NT plain", x768, wt, dict(trans_b=True)))
         out.append(("NT res", x768, wt, dict(trans_b=True, residual=r(M, 768))))
+    if "--nn-dgrad" in sys.argv:   # the input-gradient launches against a pre-transposed weight copy (k-contiguous B) beside the k-major form
+        out = []
+        for (nm, xin, n_out, k_in, extra) in [("dqkv plain", x2304, 768, 2304, {}), ("do plain", x768, 768, 768, {}),
+                                              ("dfc1 res", x3072, 768, 3072, dict(residual=r(M, 768))),
+                                              ("dfc2 mulaux+colsum", x768, 3072, 768, dict(aux=r(M, 3072), epilogue=ops.EPI_MULAUX, colsum=torch.zeros(3072, device=dev)))]:
+            w = r(k_in, n_out)                       # W stored [K][N]: the k-major operand of dX = dY W
+            out.append((nm + " NT", xin, w, dict(trans_b=True, **extra)))
+            out.append((nm + " NN", xin, w.t().contiguous(), dict(**extra)))
     return out
 
 
