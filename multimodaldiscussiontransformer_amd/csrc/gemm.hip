@@ -1616,10 +1616,11 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   p.tile_queue = nullptr;
   if (persist && nhs_total >= 12) {
     // MDT_GEMM_W4: 0 off; 1 every persistent launch; 2 the launches it is measured faster on (k-contiguous operands, light
-    // epilogues: plain, bias, residual, bias + dropout + residual — not the GELU form, not k-major operands)
+    // epilogues: plain, bias, residual, bias + dropout + residual, saved derivative + column sums — not the GELU form, not k-major operands)
     const int w4 = sw.gemm_w4;
     const int e_ = p.epilogue;
-    const bool light = e_ == 0 || e_ == MDT_EPI_BIAS || e_ == MDT_EPI_RESIDUAL || e_ == (MDT_EPI_BIAS | MDT_EPI_RESIDUAL | MDT_EPI_DROPOUT);
+    const bool light = e_ == 0 || e_ == MDT_EPI_BIAS || e_ == MDT_EPI_RESIDUAL || e_ == (MDT_EPI_BIAS | MDT_EPI_RESIDUAL | MDT_EPI_DROPOUT) ||
+                       e_ == (MDT_EPI_MULAUX | MDT_EPI_COLSUM);
     const bool use_w4 = (w4 == 1 || (w4 == 2 && !ta && !tb && light && !sw.gemm_no_spec)) && !(sw.gemm_dynamic && g_tile_queues);
     if (use_w4) {
       p.group_n = p.tiles_n;
