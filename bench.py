@@ -625,7 +625,7 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         if gs:
-            roofline = dict(bound="mfma", kernel="gemm_bf16_pp256p / gemm_bf16_pp256 (bf16 MFMA tile GEMM family: persistent 256x256 ping-pong, split-K 256x256, 128x128)", achieved=round(gs["tflops"], 1),
+            roofline = dict(bound="mfma", kernel="gemm_bf16_w4p / gemm_bf16_pp256p / gemm_bf16_pp256 (bf16 MFMA tile GEMM family: persistent 256x256 in its 4-wave and 8-wave ping-pong forms, split-K 256x256, 128x128)", achieved=round(gs["tflops"], 1),
                             peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(gs["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4),
                             traffic=traffic, traffic_unit="bytes per launch (fabric-side FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)", traffic_source=traffic_src,
                             algorithmic_bytes_per_launch=round(gs["bytes"] / gs["launches"]) if gs.get("bytes") else None, launches=gs["launches"], avg_launch_us=round(gs["avg_us"], 1),
