@@ -394,12 +394,41 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
 // GEMMs against 1.05-1.13 on the same shapes without).
 // PEND: the outputs of row tiles 4-7 are not stored but handed back packed (pend[(i - 4) * NJP + jp], 16 bytes per lane each):
 // the 4-wave kernel keeps them in registers and lets them leave during the next tile's first steps.
-template <int NJP, int EPK = -1, bool PEND = false>   // NJP pairs of 16-column tiles per wave: 2 (128x64 blocks) or 4 (128x128 blocks)
+// What a compile-time epilogue reads before it can start — the bias vectors of the wave's columns and the first column pair's
+// residual / saved-derivative vectors — requested ahead (EPF: the 4-wave kernel asks for them before its last 32-k step, whose
+// free fragment registers hold them: at the epilogue they have long arrived, and the wait in front of their first use
+// covers loads older than the last step's LDS-DMA pieces instead of every operation in flight).
+template <int EPK>
+constexpr int epi_pre_kind() { return EPK < 0 ? 0 : (EPK & (MDT_EPI_MULAUX | MDT_EPI_DGELU)) ? 1 : (EPK & MDT_EPI_RESIDUAL) ? 2 : (EPK & MDT_EPI_ACCUM) ? 3 : 0; }
+template <int NJP>
+struct EpiPre { bf16x8 bias[NJP]; bf16x8 pre[8]; };
+template <int NJP, int EPK>
+__device__ __forceinline__ void epi_prefetch(const GemmParams& p, int lane, int64_t m0w, int64_t n0w, EpiPre<NJP>& f) {
+  const int c = lane & 15, g = lane >> 4;
+  constexpr int PRE_KIND = epi_pre_kind<EPK>();
+  const int64_t gc0 = n0w + 16 * (g & 1) + 8 * (g >> 1);
+  if constexpr (EPK >= 0 && (EPK & MDT_EPI_BIAS) != 0) {
+#pragma unroll
+    for (int jp = 0; jp < NJP; ++jp) f.bias[jp] = *(const bf16x8*)((const bf16_t*)p.bias + gc0 + 32 * jp);
+  }
+  if constexpr (PRE_KIND != 0) {
+    const bf16_t* base = PRE_KIND == 1 ? (const bf16_t*)p.aux : PRE_KIND == 2 ? (const bf16_t*)p.residual : (const bf16_t*)p.C;
+    const int64_t ld = PRE_KIND == 1 ? p.ldaux : PRE_KIND == 2 ? p.ldr : p.ldc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int64_t gr = m0w + 16 * i + c;
+      gr = gr < p.M ? gr : p.M - 1;
+      f.pre[i] = *(const bf16x8*)(base + gr * ld + gc0);
+    }
+  }
+}
+
+template <int NJP, int EPK = -1, bool PEND = false, bool EPF = false>   // NJP pairs of 16-column tiles per wave: 2 (128x64 blocks) or 4 (128x128 blocks)
 __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc)[8][2 * NJP], int lane, int64_t m0w, int64_t n0w,
-                                                bf16x8* pend = nullptr) {
+                                                bf16x8* pend = nullptr, const EpiPre<NJP>* pf = nullptr) {
   const int c = lane & 15, g = lane >> 4;
   const int ep = EPK >= 0 ? EPK : p.epilogue;
-  constexpr int PRE_KIND = EPK < 0 ? 0 : (EPK & (MDT_EPI_MULAUX | MDT_EPI_DGELU)) ? 1 : (EPK & MDT_EPI_RESIDUAL) ? 2 : (EPK & MDT_EPI_ACCUM) ? 3 : 0;
+  constexpr int PRE_KIND = epi_pre_kind<EPK>();
   int64_t gcs[NJP];
   float bias[NJP][8];
 #pragma unroll
@@ -408,7 +437,9 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[jp][e] = 0.f;
     if (ep & MDT_EPI_BIAS) {
-      const bf16x8 b = *(const bf16x8*)((const bf16_t*)p.bias + gcs[jp]);
+      bf16x8 b;
+      if constexpr (EPF) b = pf->bias[jp];
+      else b = *(const bf16x8*)((const bf16_t*)p.bias + gcs[jp]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) bias[jp][e] = (float)b[e];
     }
@@ -427,7 +458,10 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
   };
   bf16x8 pre[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) pre[i] = PRE_KIND ? pre_load(i, 0) : bf16x8{};
+  for (int i = 0; i < 8; ++i) {
+    if constexpr (EPF && PRE_KIND != 0) pre[i] = pf->pre[i];
+    else pre[i] = PRE_KIND ? pre_load(i, 0) : bf16x8{};
+  }
   // The row groups are expanded by hand (generic lambda over compile-time indices): hipcc does not unroll a
   // loop around the convergent swap, and a rolled loop indexes the accumulators dynamically = 512 B of scratch per lane.
   auto row_group = [&](auto ic, auto jc) __attribute__((always_inline)) {
@@ -1160,6 +1194,27 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 //     2 MFMA, fragment read, 2 MFMA, fragment read, 2 MFMA, LDS-DMA piece, 2 MFMA
 // on one fragment set while the reads fill the other (2 400 cycles per K-tile in that probe, L2-resident operands, no
 // epilogue).  Ring, prefetch distance, tile walk and epilogue are those of gemm_bf16_pp256p; one barrier per step.
+// Fragment of a 32-k stage for the 4-wave kernel.  k-contiguous operands: the plain 16-byte read.  k-major operands: the two
+// ds_read_b64_tr_b16 halves as ASM — in front of the builtin the compiler puts s_waitcnt vmcnt(0) (an LDS read that might
+// alias what an LDS-DMA is still writing), which drains the whole prefetch ring once per fragment; the kernel orders its
+// reads behind the stage's arrival itself (counted vmcnt + barrier at the top of every step) and waits for them with its
+// own lgkmcnt(0) before the step that consumes them.
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+template <bool KM, int ROWS>
+__device__ __forceinline__ bf16x8 w4_frag(const char* lds_tile, int rc_base, int lane) {
+  if constexpr (!KM) {
+    return load_frag_h<false, ROWS>(lds_tile, rc_base, lane);
+  } else {
+    constexpr int RB = ROWS * 2;
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int blk = rc_base >> 4, k_lo = g * 8 + q;
+    const unsigned addr = (unsigned)(size_t)LDS_PTR(lds_tile + k_lo * RB + ((blk ^ swz_km(k_lo)) * 32) + pp * 8);
+    i32x2 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(lo), "=&v"(hi) : "v"(addr), "n"(4 * RB) : "memory");
+    return __builtin_bit_cast(bf16x8, i32x4{lo[0], lo[1], hi[0], hi[1]});
+  }
+}
+
 __device__ __forceinline__ void w4_dma(__amdgpu_buffer_rsrc_t rs, char* lds, unsigned voff, int soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds), 16, voff, soff, 0, 0);
 }
@@ -1255,6 +1310,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   int v_next = v + (int)gridDim.x < nvt ? v + (int)gridDim.x : -1;
   Desc cur = make_desc(v);
   bool has_next = v_next >= 0;
+#ifdef MDT_W4_STAMPS
+  // diagnostic build (-DMDT_W4_STAMPS, MDT_GEMM_STAMP=1): shader-clock stamps of every step of tiles 4 and 5 of workgroup 9,
+  // of the loop's end, the epilogue's end and the end of the fragment prime — same report as the 8-wave kernel's
+  const unsigned long long w4_t0c = __builtin_amdgcn_s_memtime(), w4_t0r = __builtin_amdgcn_s_memrealtime();
+  int tile_no = 0, n_tiles_done = 0;
+#define W4_STAMP(slot_)                                                                                         \
+  if (p.stamps && tid == 0 && blockIdx.x == 9 && (tile_no == 4 || tile_no == 5) && nhs <= 100)                \
+    p.stamps[4 * (size_t)gridDim.x + (tile_no - 4) * (nhs + 3) + (slot_)] = __builtin_amdgcn_s_memtime()
+#else
+#define W4_STAMP(slot_) (void)0
+#endif
   // after the last tile the ring keeps turning on a descriptor of zero records (every load reads as 0, nobody reads the
   // stage): the loop needs no "nothing left to request" case and the vmcnt arithmetic is the same in every step
   auto null_desc = [&](Desc d) {
@@ -1270,8 +1336,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   bf16x8 fa[2][8], fb[2][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    fa[0][i] = load_frag_h<A_KM, BM>(smem, wr * 128 + i * 16, lane);
-    fb[0][i] = load_frag_h<B_KM, BN>(smem + A_BYTES, wc * 128 + i * 16, lane);
+    fa[0][i] = w4_frag<A_KM, BM>(smem, wr * 128 + i * 16, lane);
+    fb[0][i] = w4_frag<B_KM, BN>(smem + A_BYTES, wc * 128 + i * 16, lane);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   int b_next = 1, b_wr = PP_DIST % PP_NB;
@@ -1282,6 +1348,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // M fall outside it and are dropped).  The other half is stored at the tile's end as before: the burst is half as long.
   constexpr bool PEND = EPK >= 0;                  // the specialised epilogues (the runtime-flag kernel keeps the plain form)
   bf16x8 pend[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) pend[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, 0, 0x00020000);
   const int c_lane = lane & 15, g_lane = lane >> 4;
   const unsigned voffP = (unsigned)((wr * 128 + c_lane) * (p.ldc * 2) + (wc * 128 + 16 * (g_lane & 1) + 8 * (g_lane >> 1)) * 2);
@@ -1314,9 +1382,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
       W4_MF(b, 0); W4_MF(b, 1);
-      if constexpr (LD) fa[ns][b] = load_frag_h<A_KM, BM>(tn, wr * 128 + b * 16, lane);
+      if constexpr (LD) fa[ns][b] = w4_frag<A_KM, BM>(tn, wr * 128 + b * 16, lane);
       W4_MF(b, 2); W4_MF(b, 3);
-      if constexpr (LD) fb[ns][b] = load_frag_h<B_KM, BN>(tn + A_BYTES, wc * 128 + b * 16, lane);
+      if constexpr (LD) fb[ns][b] = w4_frag<B_KM, BN>(tn + A_BYTES, wc * 128 + b * 16, lane);
       W4_MF(b, 4); W4_MF(b, 5);
       issue_piece(d_issue, sa, sb, b_wr, b);
       if constexpr (ST >= 0) {
@@ -1343,16 +1411,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bool same = tgt < nhs;
     Desc d = nxt;
     if (same) d = cur;
+    W4_STAMP(hs);
     step(cs_c, first_c, nw_c, st_c, ld_c, d, same ? tgt : tgt - nhs);
   };
 #define W4_N(n_) std::integral_constant<int, n_> {}
-  bool have_pend = false;
   for (;;) {
     // K is a multiple of 64: a tile has an even number of 32-k steps, so every tile starts on fragment set 0.
     // vmcnt budgets: a step issues 8 pieces, and 2 stores while pending vectors leave (steps 0-7 after a tile of this
     // workgroup): pieces of the next step were requested three steps ago, so what may be in flight is what the two steps in
     // between issued — 16, 18 or 20 operations.
-    if (PEND && have_pend) {
+    // The first tile of a workgroup walks the same ten steps: its sixteen "pending" vectors are zeros sent through a descriptor
+    // of zero records (dropped by the bounds check, counted by vmcnt like any store).  A separate first-tile path cost more than
+    // its code: the compiler parked registers in scratch around it and, where the two paths met, drained the whole prefetch ring
+    // (s_waitcnt vmcnt(0)) once per TILE.
+    if constexpr (PEND) {
       run_step(C0{}, T_{}, W4_N(16), W4_N(0), T_{}, 0);
       run_step(C1{}, F_{}, W4_N(18), W4_N(2), T_{}, 1);
       run_step(C0{}, F_{}, W4_N(20), W4_N(4), T_{}, 2);
@@ -1377,19 +1449,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     run_step(C0{}, F_{}, W4_N(16), W4_N(-1), T_{}, nhs - 2);
     const int b_prime = b_next;                   // the stage holding the next tile's first step
+    EpiPre<4> epf;
+    if constexpr (PEND) epi_prefetch<4, EPK>(p, lane, cur.m0 + wr * 128, cur.n0 + wc * 128, epf);
     run_step(C1{}, F_{}, W4_N(16), W4_N(-1), F_{}, nhs - 1);
-    direct_epilogue<4, EPK, PEND>(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 128, pend);
+    W4_STAMP(nhs);
+    direct_epilogue<4, EPK, PEND, PEND>(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 128, pend, &epf);
+    W4_STAMP(nhs + 1);
     {                                             // fragments of the next tile's first step (its stage landed a step ago)
       const char* t0 = smem + b_prime * PP_STAGE;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        fa[0][i] = load_frag_h<A_KM, BM>(t0, wr * 128 + i * 16, lane);
-        fb[0][i] = load_frag_h<B_KM, BN>(t0 + A_BYTES, wc * 128 + i * 16, lane);
+        fa[0][i] = w4_frag<A_KM, BM>(t0, wr * 128 + i * 16, lane);
+        fb[0][i] = w4_frag<B_KM, BN>(t0 + A_BYTES, wc * 128 + i * 16, lane);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    W4_STAMP(nhs + 2);
+#ifdef MDT_W4_STAMPS
+    ++tile_no; ++n_tiles_done;
+#endif
     if constexpr (PEND) {
-      if (has_next) { rsP = desc_c(cur); have_pend = true; }
+      if (has_next) rsP = desc_c(cur);
       else {                                      // nothing follows: the pending half leaves now
         const __amdgpu_buffer_rsrc_t rl = desc_c(cur);
 #pragma unroll
@@ -1404,6 +1484,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     has_next = v_next >= 0;
     nxt = has_next ? make_desc(v_next) : null_desc(cur);
   }
+#ifdef MDT_W4_STAMPS
+  if (p.stamps && tid == 0) {
+    unsigned long long* o = p.stamps + 4 * (size_t)blockIdx.x;
+    o[0] = __builtin_amdgcn_s_memtime() - w4_t0c;
+    o[1] = __builtin_amdgcn_s_memrealtime() - w4_t0r;
+    o[2] = (unsigned long long)n_tiles_done * (nhs / 2);
+    o[3] = w4_t0r;
+  }
+#endif
+#undef W4_STAMP
 #undef W4_N
 #undef W4_MF
 }
@@ -1621,8 +1711,14 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
     const int e_ = p.epilogue;
     const bool light = e_ == 0 || e_ == MDT_EPI_BIAS || e_ == MDT_EPI_RESIDUAL || e_ == (MDT_EPI_BIAS | MDT_EPI_RESIDUAL | MDT_EPI_DROPOUT) ||
                        e_ == (MDT_EPI_MULAUX | MDT_EPI_COLSUM);
-    const bool use_w4 = (w4 == 1 || (w4 == 2 && !ta && !tb && light && !sw.gemm_no_spec)) && !(sw.gemm_dynamic && g_tile_queues);
+    const bool use_w4 = (w4 == 1 || (w4 == 2 && !ta && light && !sw.gemm_no_spec)) && !(sw.gemm_dynamic && g_tile_queues);
     if (use_w4) {
+#ifdef MDT_W4_STAMPS
+      if (sw.gemm_stamp) {
+        if (hipMalloc(&p.stamps, (size_t)grid.x * 32 + 256 * 8) != hipSuccess) { (void)hipGetLastError(); p.stamps = nullptr; }
+        else (void)hipMemsetAsync(p.stamps, 0, (size_t)grid.x * 32 + 256 * 8, st);
+      }
+#endif
       p.group_n = p.tiles_n;
       {
         const double b_panel = 256.0 * (double)p.k_chunk * 2.0;
@@ -1664,6 +1760,9 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
       } else if (ta && !tb) LW4(true, false, -1)
       else LW4(true, true, -1)
 #undef LW4
+#ifdef MDT_W4_STAMPS
+      if (p.stamps) { report_stamps(p.stamps, grid.x, p); (void)hipFree(p.stamps); }
+#endif
       return check_launch("gemm_bf16_w4p");
     }
   }
