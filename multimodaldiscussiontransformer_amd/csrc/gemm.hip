@@ -1306,6 +1306,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int q = 0; q < 8; ++q) issue_piece(d, sa, sb, buf, q);
   };
 
+  if (p.epilogue & (1 << 26)) {   // diagnostic (MDT_GEMM_DIAG=64): skew whole XCDs against each other (their workgroups stay in phase)
+    const int steps = (blockIdx.x & 7) * ((nhs + 12) / 8);
+    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(28);
+  }
   int v = blockIdx.x;
   int v_next = v + (int)gridDim.x < nvt ? v + (int)gridDim.x : -1;
   Desc cur = make_desc(v);
@@ -1708,7 +1712,7 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
     // MDT_GEMM_W4: 0 off; 1 every persistent launch; 2 the launches it is measured faster on (k-contiguous operands, light
     // epilogues: plain, bias, residual, bias + dropout + residual, saved derivative + column sums — not the GELU form, not k-major operands)
     const int w4 = sw.gemm_w4;
-    const int e_ = p.epilogue;
+    const int e_ = p.epilogue & ((1 << 22) - 1);   // start-skew diagnostics (bits 22+) keep the compile-time epilogues
     const bool light = e_ == 0 || e_ == MDT_EPI_BIAS || e_ == MDT_EPI_RESIDUAL || e_ == (MDT_EPI_BIAS | MDT_EPI_RESIDUAL | MDT_EPI_DROPOUT) ||
                        e_ == (MDT_EPI_MULAUX | MDT_EPI_COLSUM);
     const bool use_w4 = (w4 == 1 || (w4 == 2 && !ta && light && !sw.gemm_no_spec)) && !(sw.gemm_dynamic && g_tile_queues);
@@ -1743,7 +1747,7 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
       constexpr int E_BIAS = MDT_EPI_BIAS, E_DENSE = MDT_EPI_BIAS | MDT_EPI_RESIDUAL | MDT_EPI_DROPOUT,
                     E_FC1 = MDT_EPI_BIAS | MDT_EPI_GELU | MDT_EPI_AUX_GRAD, E_RES = MDT_EPI_RESIDUAL,
                     E_DFC2 = MDT_EPI_MULAUX | MDT_EPI_COLSUM;
-      const int e = sw.gemm_no_spec ? -2 : p.epilogue;
+      const int e = sw.gemm_no_spec ? -2 : (p.epilogue & ((1 << 22) - 1));
       if (!ta && !tb) {
         if (e == E_BIAS) LW4(false, false, E_BIAS)
         else if (e == E_DENSE) LW4(false, false, E_DENSE)
@@ -1840,7 +1844,7 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
     constexpr int E_BIAS = MDT_EPI_BIAS, E_DENSE = MDT_EPI_BIAS | MDT_EPI_RESIDUAL | MDT_EPI_DROPOUT,
                   E_FC1 = MDT_EPI_BIAS | MDT_EPI_GELU | MDT_EPI_AUX_GRAD /* HF blocks have no activation dropout */, E_RES = MDT_EPI_RESIDUAL,
                   E_DFC2 = MDT_EPI_MULAUX | MDT_EPI_COLSUM;
-    const int e = sw.gemm_no_spec ? -2 : p.epilogue;
+    const int e = sw.gemm_no_spec ? -2 : (p.epilogue & ((1 << 22) - 1));
     if (!ta && !tb) {
       if (e == E_BIAS) LPS(false, false, E_BIAS)
       else if (e == E_DENSE) LPS(false, false, E_DENSE)

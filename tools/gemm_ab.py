@@ -91,6 +91,8 @@ def main():
             N = b.shape[1] if kw.get("trans_b") else b.shape[0]
             K = a.shape[1]
             res = []
+            setenv(**{k: VARIANTS[0].get(k) for k in NAMES})      # throw-away pass: the first timed variant of a row otherwise
+            timeit(lambda: ops.gemm(a, b, **dict(kw)), iters=10)  # pays the clock ramp / cold caches (3-10 % on these launches)
             for var in VARIANTS:
                 setenv(**{k: var.get(k) for k in NAMES})
                 kw2 = dict(kw)
