@@ -287,7 +287,7 @@ _LN_BIAS_RIDE = os.environ.get("MDT_LN_BIAS_RIDE", "1") != "0"    # 0: those sum
 
 # ------------------------------------------------------------------------------------------
 # input gradients against a transposed weight copy
-_NN_DGRAD = os.environ.get("MDT_NN_DGRAD", "1") != "0"     # 0: dX = dY W always reads W in place (k-major operand) — A/B runs
+_NN_DGRAD = os.environ.get("MDT_NN_DGRAD", "0") == "1"     # 1: the big launches read W through a transposed copy (A/B runs)
 _WT_CACHE: dict = {}
 WEIGHT_EPOCH = 0            # bumped by whoever rewrites weights behind torch's back (optim.FusedAdam.step)
 
@@ -311,11 +311,11 @@ def _transposed(w: torch.nn.Parameter) -> torch.Tensor:
 
 
 def dgrad(dy: torch.Tensor, w: torch.nn.Parameter, **kw) -> torch.Tensor:
-    """dX[M, in] = dY[M, out] @ W[out, in] (+ epilogue).  For the big launches the weight is read through a transposed
-    bf16 copy, so that both operands are k-contiguous: the k-major form costs the GEMM 4-8 % (two ds_read_b64_tr_b16 per
-    fragment) and the 4-wave kernel takes k-contiguous operands only; the copies (2 bytes per block parameter, one
-    transpose per optimiser step) are negligible beside that.  Small problems and the o projection (768 x 768) read W in
-    place."""
+    """dX[M, in] = dY[M, out] @ W[out, in] (+ epilogue).  W is read in place as the k-major operand: since the 4-wave
+    kernel reads k-major fragments with asm ds_read_b64_tr_b16 pairs (gemm.hip, w4_frag) that form runs as fast as the
+    k-contiguous one (tools/gemm_ab.py --nn-dgrad; whole step 137.9 / 138.0 ms either way in one call).  MDT_NN_DGRAD=1
+    keeps the earlier route for A/B runs: the big launches read a transposed bf16 copy of W, cached until the weight
+    changes (2 bytes per block parameter, one transpose per optimiser step)."""
     if _NN_DGRAD and dy.dtype == torch.bfloat16 and dy.shape[0] >= 8192 and w.shape[0] * w.shape[1] >= 1_500_000:
         return ops.gemm(dy, _transposed(w), **kw)
     return ops.gemm(dy, w.data, trans_b=True, **kw)
