@@ -88,6 +88,15 @@ __device__ __forceinline__ float row16_sum(float v) {
   for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// the same sum through DPP row rotations (a DPP row = 16 lanes): no LDS permutes, no lane numbers to keep alive — every lane
+// of the row ends up with the total (summation order differs from row16_sum's butterfly in the last bit)
+__device__ __forceinline__ float row16_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));   // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xf, 0xf, true));   // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x122, 0xf, 0xf, true));   // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x121, 0xf, 0xf, true));   // row_ror:1
+  return v;
+}
 __device__ __forceinline__ float row16_max(float v) {
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

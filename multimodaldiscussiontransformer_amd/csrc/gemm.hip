@@ -402,8 +402,22 @@ template <int EPK>
 constexpr int epi_pre_kind() { return EPK < 0 ? 0 : (EPK & (MDT_EPI_MULAUX | MDT_EPI_DGELU)) ? 1 : (EPK & MDT_EPI_RESIDUAL) ? 2 : (EPK & MDT_EPI_ACCUM) ? 3 : 0; }
 template <int NJP>
 struct EpiPre { bf16x8 bias[NJP]; bf16x8 pre[8]; };
-template <int NJP, int EPK>
-__device__ __forceinline__ void epi_prefetch(const GemmParams& p, int lane, int64_t m0w, int64_t n0w, EpiPre<NJP>& f) {
+// C (stores), X (saved-derivative stores), R (the tensor the epilogue reads: saved derivative / residual / C): descriptors based
+// at the tile's origin, one 32-bit per-lane offset each, row tile and column pair as immediate offsets
+struct EpiBuf { __amdgpu_buffer_rsrc_t rsC, rsX, rsR; unsigned voffC, voffX, voffR; int ldc16, ldx16, ldr16; };
+// A 16-byte buffer store whose data registers may be rewritten right behind it.  hipcc (ROCm 7.2) takes a MUBUF store with
+// an SGPR soffset to be free of the "store of more than 8 bytes, then VALU write of its data registers" hazard and puts the
+// next VALU write directly behind it; on gfx950 that store then wrote the NEW contents of its second dword for the last lanes
+// (tests: one 16 x 32 block per tile wrong in two elements of four rows).  The asm holds the data registers for three more
+// wait states, whatever the scheduler does.
+__device__ __forceinline__ void epi_store16(i32x4 v, __amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 2" ::"v"(v) : "memory");
+#endif
+}
+template <int NJP, int EPK, bool PEND = false>
+__device__ __forceinline__ void epi_prefetch(const GemmParams& p, int lane, int64_t m0w, int64_t n0w, EpiPre<NJP>& f, const EpiBuf* eb = nullptr) {
   const int c = lane & 15, g = lane >> 4;
   constexpr int PRE_KIND = epi_pre_kind<EPK>();
   const int64_t gc0 = n0w + 16 * (g & 1) + 8 * (g >> 1);
@@ -416,16 +430,33 @@ __device__ __forceinline__ void epi_prefetch(const GemmParams& p, int lane, int6
     const int64_t ld = PRE_KIND == 1 ? p.ldaux : PRE_KIND == 2 ? p.ldr : p.ldc;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      int64_t gr = m0w + 16 * i + c;
-      gr = gr < p.M ? gr : p.M - 1;
-      f.pre[i] = *(const bf16x8*)(base + gr * ld + gc0);
+      if constexpr (PEND) {
+        f.pre[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(eb->rsR, eb->voffR, i * eb->ldr16, 0));
+      } else {
+        int64_t gr = m0w + 16 * i + c;
+        gr = gr < p.M ? gr : p.M - 1;
+        f.pre[i] = *(const bf16x8*)(base + gr * ld + gc0);
+      }
     }
   }
 }
 
+// PEND kernels store through buffer descriptors based at the tile's origin (EpiBuf): rows past M fall outside the
+// descriptor and are dropped by its bounds check, so there is no per-row-group branch and — what the 4-wave kernel's
+// vmcnt arithmetic needs — the NUMBER of stores a wave issues per tile is a constant.
 template <int NJP, int EPK = -1, bool PEND = false, bool EPF = false>   // NJP pairs of 16-column tiles per wave: 2 (128x64 blocks) or 4 (128x128 blocks)
 __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc)[8][2 * NJP], int lane, int64_t m0w, int64_t n0w,
-                                                bf16x8* pend = nullptr, const EpiPre<NJP>* pf = nullptr) {
+                                                bf16x8* pend = nullptr, const EpiPre<NJP>* pf = nullptr, const EpiBuf* eb = nullptr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // everything derived from the lane number is recomputed here, per tile: left alone the compiler hoists the per-lane address
+  // parts (64-bit) out of the persistent tile loop, keeps them alive through the K loop and ends up parking them in scratch
+  // (the lane number itself too: two mbcnt on an opaque zero instead of one more register carried through the loop)
+  if constexpr (PEND) {
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z));
+  }
+#endif
   const int c = lane & 15, g = lane >> 4;
   const int ep = EPK >= 0 ? EPK : p.epilogue;
   constexpr int PRE_KIND = epi_pre_kind<EPK>();
@@ -452,10 +483,16 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
   auto pre_load = [&](int i, int jp) -> bf16x8 {
     const bf16_t* base = PRE_KIND == 1 ? (const bf16_t*)p.aux : PRE_KIND == 2 ? (const bf16_t*)p.residual : (const bf16_t*)p.C;
     const int64_t ld = PRE_KIND == 1 ? p.ldaux : PRE_KIND == 2 ? p.ldr : p.ldc;
-    int64_t gr = m0w + 16 * i + c;
-    gr = gr < p.M ? gr : p.M - 1;                // rows past the end: any valid address, the value is never used
-    return *(const bf16x8*)(base + gr * ld + gcs[jp]);
+    if constexpr (PEND) {                          // rows past the end read as zeros
+      return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(eb->rsR, eb->voffR, i * eb->ldr16 + jp * 64, 0));
+    } else {
+      int64_t gr = m0w + 16 * i + c;
+      gr = gr < p.M ? gr : p.M - 1;                // rows past the end: any valid address, the value is never used
+      return *(const bf16x8*)(base + gr * ld + gcs[jp]);
+    }
   };
+  const int64_t rows_left64 = p.M - m0w;           // uniform over the wave
+  const int rows_left = rows_left64 > 0x40000000 ? 0x40000000 : (int)rows_left64;
   bf16x8 pre[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -468,7 +505,7 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
     constexpr int i = decltype(ic)::value;
     constexpr int jp = decltype(jc)::value;
     const int64_t gr = m0w + 16 * i + c;
-    const bool live = gr < p.M;
+    const bool live = 16 * i + c < rows_left;      // 32-bit on purpose: eight hoisted 64-bit row numbers per lane ended up in scratch
     const bf16x8 pv = pre[i];
     if (PRE_KIND && jp + 1 < NJP) pre[i] = pre_load(i, jp + 1);
     do {
@@ -484,9 +521,8 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
         v[r] = lo;
         v[4 + r] = hi;
       }
-      if (!live) {
-        if constexpr (PEND && i >= 4) pend[(i - 4) * NJP + jp] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};   // the store drops rows past M
-        break;
+      if constexpr (!PEND) {
+        if (!live) break;
       }
       const int64_t gc = gcs[jp];
 #pragma unroll
@@ -508,7 +544,11 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
           dg[e] = (bf16_t)(__builtin_fmaf(v[e], pdf, cdf) * sc8[e]);
           v[e] = v[e] * cdf * sc8[e];
         }
-        if (p.aux) *(bf16x8*)((bf16_t*)p.aux + gr * p.ldaux + gc) = dg;
+        if constexpr (PEND) {
+          if (p.aux) epi_store16(__builtin_bit_cast(i32x4, dg), eb->rsX, eb->voffX, i * eb->ldx16 + jp * 64);
+        } else {
+          if (p.aux) *(bf16x8*)((bf16_t*)p.aux + gr * p.ldaux + gc) = dg;
+        }
       } else {
       if (ep & MDT_EPI_GELU) {
         if (p.aux) {
@@ -547,7 +587,7 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
       }
       if (ep & MDT_EPI_COLSUM) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) cs[jp][e] += v[e];
+        for (int e = 0; e < 8; ++e) cs[jp][e] += (!PEND || live) ? v[e] : 0.f;
       }
       bf16_t* cptr = (bf16_t*)p.C + gr * p.ldc + gc;
       if (ep & MDT_EPI_ACCUM) {
@@ -558,7 +598,11 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-      if constexpr (PEND && i >= 4) { pend[(i - 4) * NJP + jp] = o; break; }
+      if constexpr (PEND) {
+        if constexpr (i >= 4) pend[(i - 4) * NJP + jp] = o;
+        else epi_store16(__builtin_bit_cast(i32x4, o), eb->rsC, eb->voffC, i * eb->ldc16 + jp * 64);
+        break;
+      }
       if (ep & (1 << 20)) break;                          // diagnostic: no output store
       if (ep & (1 << 21)) {                               // diagnostic: write-through, do not keep the line in L2
         const i32x4 raw = __builtin_bit_cast(i32x4, o);
@@ -591,8 +635,9 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
     for (int jp = 0; jp < NJP; ++jp)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float s_ = row16_sum(cs[jp][e]);
-        if (c == 0) atomicAdd(p.colsum + gcs[jp] + e, s_);
+        const float s_ = row16_sum_dpp(cs[jp][e]);
+        // uniform 64-bit base + 32-bit lane offset: the per-lane 64-bit column numbers otherwise live through the whole K loop
+        if (c == 0) atomicAdd(p.colsum + n0w + (32 * jp + 16 * (g & 1) + 8 * (g >> 1) + e), s_);
       }
   }
 }
@@ -1346,6 +1391,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   int b_next = 1, b_wr = PP_DIST % PP_NB;
   f32x4 acc[8][8];
+  constexpr int W4_DS = 16;                        // direct stores of an epilogue (row tiles 0-3 x 4 column pairs): a constant, see EpiBuf
 
   // Pending outputs: row tiles 4-7 of a finished tile stay packed in registers (16 vectors of 16 bytes per lane) and
   // leave two per step during steps 0-7 of the next tile, through a buffer descriptor based at the tile's origin (rows past
@@ -1358,6 +1404,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int c_lane = lane & 15, g_lane = lane >> 4;
   const unsigned voffP = (unsigned)((wr * 128 + c_lane) * (p.ldc * 2) + (wc * 128 + 16 * (g_lane & 1) + 8 * (g_lane >> 1)) * 2);
   const int ldc16 = (int)(p.ldc * 2 * 16);         // bytes between row tiles
+  if constexpr (PEND) {
+    // Steps 0-2 of a tile count the epilogue's W4_DS direct stores among the operations that may still be in flight (they are
+    // younger than the LDS-DMA pieces those steps wait for; without counting them the steps would wait for the stores'
+    // acknowledgements instead).  A workgroup's first tile has no epilogue before it: W4_DS dropped stores stand in.
+#pragma unroll
+    for (int i = 0; i < W4_DS; ++i) __builtin_amdgcn_raw_buffer_store_b128(i32x4{0, 0, 0, 0}, rsP, voffP, 0, 0);
+  }
   auto desc_c = [&](const Desc& d) {
     const int64_t bytes = (p.M - d.m0) * p.ldc * 2 - d.n0 * 2;
     return __builtin_amdgcn_make_buffer_rsrc((void*)((bf16_t*)p.C + d.m0 * p.ldc + d.n0), 0,
@@ -1429,9 +1482,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // its code: the compiler parked registers in scratch around it and, where the two paths met, drained the whole prefetch ring
     // (s_waitcnt vmcnt(0)) once per TILE.
     if constexpr (PEND) {
-      run_step(C0{}, T_{}, W4_N(16), W4_N(0), T_{}, 0);
-      run_step(C1{}, F_{}, W4_N(18), W4_N(2), T_{}, 1);
-      run_step(C0{}, F_{}, W4_N(20), W4_N(4), T_{}, 2);
+      run_step(C0{}, T_{}, W4_N(16 + W4_DS), W4_N(0), T_{}, 0);
+      run_step(C1{}, F_{}, W4_N(18 + W4_DS), W4_N(2), T_{}, 1);
+      run_step(C0{}, F_{}, W4_N(20 + W4_DS), W4_N(4), T_{}, 2);
       run_step(C1{}, F_{}, W4_N(20), W4_N(6), T_{}, 3);
       run_step(C0{}, F_{}, W4_N(20), W4_N(8), T_{}, 4);
       run_step(C1{}, F_{}, W4_N(20), W4_N(10), T_{}, 5);
@@ -1454,10 +1507,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     run_step(C0{}, F_{}, W4_N(16), W4_N(-1), T_{}, nhs - 2);
     const int b_prime = b_next;                   // the stage holding the next tile's first step
     EpiPre<4> epf;
-    if constexpr (PEND) epi_prefetch<4, EPK>(p, lane, cur.m0 + wr * 128, cur.n0 + wc * 128, epf);
+    EpiBuf eb;
+    if constexpr (PEND) {
+      auto desc_of = [&](const void* base, int64_t ld) {
+        const int64_t bytes = (p.M - cur.m0) * ld * 2 - cur.n0 * 2;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)((bf16_t*)base + cur.m0 * ld + cur.n0), 0,
+                                                 (unsigned)(bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : bytes), 0x00020000);
+      };
+      auto voff_of = [&](int64_t ld) { return (unsigned)((wr * 128 + c_lane) * (ld * 2) + (wc * 128 + 16 * (g_lane & 1) + 8 * (g_lane >> 1)) * 2); };
+      eb.rsC = desc_of(p.C, p.ldc); eb.voffC = voffP; eb.ldc16 = ldc16;
+      eb.rsX = eb.rsC; eb.voffX = voffP; eb.ldx16 = ldc16;
+      eb.rsR = eb.rsC; eb.voffR = voffP; eb.ldr16 = ldc16;
+      if constexpr ((EPK & MDT_EPI_AUX_GRAD) != 0) { eb.rsX = desc_of(p.aux, p.ldaux); eb.voffX = voff_of(p.ldaux); eb.ldx16 = (int)(p.ldaux * 32); }
+      constexpr int PK = epi_pre_kind<EPK>();
+      if constexpr (PK == 1) { eb.rsR = desc_of(p.aux, p.ldaux); eb.voffR = voff_of(p.ldaux); eb.ldr16 = (int)(p.ldaux * 32); }
+      if constexpr (PK == 2) { eb.rsR = desc_of(p.residual, p.ldr); eb.voffR = voff_of(p.ldr); eb.ldr16 = (int)(p.ldr * 32); }
+      epi_prefetch<4, EPK, true>(p, lane, cur.m0 + wr * 128, cur.n0 + wc * 128, epf, &eb);
+    }
     run_step(C1{}, F_{}, W4_N(16), W4_N(-1), F_{}, nhs - 1);
     W4_STAMP(nhs);
-    direct_epilogue<4, EPK, PEND, PEND>(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 128, pend, &epf);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The MFMAs are asm statements: the compiler does not know that their results need wait states before a VALU may read
+    // them, and it is free to hoist an accumulator read of the epilogue up to right behind the last MFMA that wrote it
+    // (seen: v_accvgpr_read three instructions after the MFMA — a stale value in one element per lane of one row group).
+    // So: the wait states by hand, and every accumulator re-defined behind them, which pins all epilogue reads below.
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7]));
+#endif
+    direct_epilogue<4, EPK, PEND, PEND>(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 128, pend, &epf, &eb);
     W4_STAMP(nhs + 1);
     {                                             // fragments of the next tile's first step (its stage landed a step ago)
       const char* t0 = smem + b_prime * PP_STAGE;
@@ -1473,9 +1552,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     ++tile_no; ++n_tiles_done;
 #endif
     if constexpr (PEND) {
-      if (has_next) rsP = desc_c(cur);
+      if (has_next) rsP = eb.rsC;
       else {                                      // nothing follows: the pending half leaves now
-        const __amdgpu_buffer_rsrc_t rl = desc_c(cur);
+        const __amdgpu_buffer_rsrc_t rl = eb.rsC;
 #pragma unroll
         for (int idx = 0; idx < 16; ++idx)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, pend[idx]), rl, voffP, (4 + (idx >> 2)) * ldc16 + (idx & 3) * 64, 0);

@@ -122,7 +122,8 @@ def test_gemm_wgrad_with_bias_gradient_riding(ops, rows, N, K, split):
     torch.testing.assert_close(gb.cpu(), ref_b, atol=2e-3 * (rows ** 0.5), rtol=1e-4)
 
 
-@pytest.mark.parametrize("tb,kind", [(False, "bias"), (False, "dense"), (True, "plain"), (True, "res")])
+@pytest.mark.parametrize("tb,kind", [(False, "bias"), (False, "dense"), (True, "plain"), (True, "res"), (False, "res"), (False, "plain"),
+                                     (True, "mulaux"), (False, "mulaux"), (False, "gelu")])
 def test_gemm_four_wave_form_is_bit_identical(ops, tb, kind, monkeypatch):
     """MDT_GEMM_W4: the 4-wave persistent kernel (gemm_bf16_w4p: one wave per SIMD, 128 x 128 per wave, hand-ordered
     MFMA / fragment-read / LDS-DMA stream, half of a finished tile leaving during the next tile's first steps) accumulates
@@ -140,16 +141,30 @@ def test_gemm_four_wave_form_is_bit_identical(ops, tb, kind, monkeypatch):
         kw["residual"] = dev(rnd(M, N, seed=34).to(bf))
     if kind == "dense":
         kw.update(drop_p=0.4, drop_seed=7)
-    outs = []
+    if kind == "mulaux":                             # fc2's input gradient: saved derivative x product, bias-gradient column sums
+        kw.update(aux=dev(rnd(M, N, seed=35).to(bf)), epilogue=ops.EPI_MULAUX)
+    if kind == "gelu":                               # fc1 forward: two outputs
+        kw.update(bias=dev(rnd(N, seed=33).to(bf)), epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD)
+    outs, extra = [], []
     try:
         for v in ("0", "1"):
             monkeypatch.setenv("MDT_GEMM_W4", v)
             L.reload_env()
-            outs.append(ops.gemm(a, b, **kw).clone())
+            kw2 = dict(kw)
+            if kind == "mulaux":
+                kw2["colsum"] = torch.zeros(N, device="cuda", dtype=torch.float32)
+            if kind == "gelu":
+                kw2["aux"] = torch.empty(M, N, device="cuda", dtype=bf)
+            outs.append(ops.gemm(a, b, **kw2).clone())
+            extra.append(kw2.get("colsum", kw2.get("aux") if kind == "gelu" else None))
     finally:
         monkeypatch.delenv("MDT_GEMM_W4")
         L.reload_env()
     assert torch.equal(outs[0], outs[1])
+    if kind == "gelu":
+        assert torch.equal(extra[0], extra[1])
+    if kind == "mulaux":                             # fp32 atomics: the order of the partial sums differs
+        torch.testing.assert_close(extra[0], extra[1], atol=2e-2, rtol=1e-3)
     ref = a.float() @ (b.float() if tb else b.float().t())
     if kind == "plain":
         torch.testing.assert_close(outs[1].float(), ref, atol=0.5, rtol=2e-2)
