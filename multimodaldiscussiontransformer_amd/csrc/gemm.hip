@@ -1394,7 +1394,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int W4_DS = 16;                        // direct stores of an epilogue (row tiles 0-3 x 4 column pairs): a constant, see EpiBuf
 
   // Pending outputs: row tiles 4-7 of a finished tile stay packed in registers (16 vectors of 16 bytes per lane) and
-  // leave two per step during steps 0-7 of the next tile, through a buffer descriptor based at the tile's origin (rows past
+  // leave one per step during steps 0-15 of the next tile, through a buffer descriptor based at the tile's origin (rows past
   // M fall outside it and are dropped).  The other half is stored at the tile's end as before: the burst is half as long.
   constexpr bool PEND = EPK >= 0;                  // the specialised epilogues (the runtime-flag kernel keeps the plain form)
   bf16x8 pend[16];
@@ -1445,11 +1445,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       W4_MF(b, 4); W4_MF(b, 5);
       issue_piece(d_issue, sa, sb, b_wr, b);
       if constexpr (ST >= 0) {
-        if (b == 2 || b == 6) {
-          constexpr int dummy = 0; (void)dummy;
-          const int idx = ST + (b == 6 ? 1 : 0);       // pending vector -> row tile 4 + idx / 4, column pair idx % 4
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, pend[ST + (b == 6 ? 1 : 0)]), rsP, voffP,
-                                                 (4 + (idx >> 2)) * ldc16 + (idx & 3) * 64, 0);
+        if (b == 4) {                                // pending vector ST -> row tile 4 + ST / 4, column pair ST % 4
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, pend[ST]), rsP, voffP, (4 + (ST >> 2)) * ldc16 + (ST & 3) * 64, 0);
         }
       }
       W4_MF(b, 6); W4_MF(b, 7);
@@ -1474,33 +1471,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_N(n_) std::integral_constant<int, n_> {}
   for (;;) {
     // K is a multiple of 64: a tile has an even number of 32-k steps, so every tile starts on fragment set 0.
-    // vmcnt budgets: a step issues 8 pieces, and 2 stores while pending vectors leave (steps 0-7 after a tile of this
-    // workgroup): pieces of the next step were requested three steps ago, so what may be in flight is what the two steps in
-    // between issued — 16, 18 or 20 operations.
-    // The first tile of a workgroup walks the same ten steps: its sixteen "pending" vectors are zeros sent through a descriptor
+    // vmcnt budgets: a step issues 8 pieces, and 1 store while pending vectors leave (steps 0-15 after a tile of this
+    // workgroup; in-call A/B: one vector per step over sixteen steps beats two per step over eight by 1-3 % on the K = 768
+    // launches): pieces of the next step were requested three steps ago, so what may be in flight is what the two steps in
+    // between issued — 16, 17 or 18 operations (+ the epilogue's W4_DS direct stores in a tile's first three steps).
+    // The first tile of a workgroup walks the same eighteen steps: its sixteen "pending" vectors are zeros sent through a descriptor
     // of zero records (dropped by the bounds check, counted by vmcnt like any store).  A separate first-tile path cost more than
     // its code: the compiler parked registers in scratch around it and, where the two paths met, drained the whole prefetch ring
     // (s_waitcnt vmcnt(0)) once per TILE.
     if constexpr (PEND) {
       run_step(C0{}, T_{}, W4_N(16 + W4_DS), W4_N(0), T_{}, 0);
-      run_step(C1{}, F_{}, W4_N(18 + W4_DS), W4_N(2), T_{}, 1);
-      run_step(C0{}, F_{}, W4_N(20 + W4_DS), W4_N(4), T_{}, 2);
-      run_step(C1{}, F_{}, W4_N(20), W4_N(6), T_{}, 3);
-      run_step(C0{}, F_{}, W4_N(20), W4_N(8), T_{}, 4);
-      run_step(C1{}, F_{}, W4_N(20), W4_N(10), T_{}, 5);
-      run_step(C0{}, F_{}, W4_N(20), W4_N(12), T_{}, 6);
-      run_step(C1{}, F_{}, W4_N(20), W4_N(14), T_{}, 7);
-      run_step(C0{}, F_{}, W4_N(20), W4_N(-1), T_{}, 8);
-      run_step(C1{}, F_{}, W4_N(18), W4_N(-1), T_{}, 9);
+      run_step(C1{}, F_{}, W4_N(17 + W4_DS), W4_N(1), T_{}, 1);
+      run_step(C0{}, F_{}, W4_N(18 + W4_DS), W4_N(2), T_{}, 2);
+      run_step(C1{}, F_{}, W4_N(18), W4_N(3), T_{}, 3);
+      run_step(C0{}, F_{}, W4_N(18), W4_N(4), T_{}, 4);
+      run_step(C1{}, F_{}, W4_N(18), W4_N(5), T_{}, 5);
+      run_step(C0{}, F_{}, W4_N(18), W4_N(6), T_{}, 6);
+      run_step(C1{}, F_{}, W4_N(18), W4_N(7), T_{}, 7);
+      run_step(C0{}, F_{}, W4_N(18), W4_N(8), T_{}, 8);
+      run_step(C1{}, F_{}, W4_N(18), W4_N(9), T_{}, 9);
+      run_step(C0{}, F_{}, W4_N(18), W4_N(10), T_{}, 10);
+      run_step(C1{}, F_{}, W4_N(18), W4_N(11), T_{}, 11);
+      run_step(C0{}, F_{}, W4_N(18), W4_N(12), T_{}, 12);
+      run_step(C1{}, F_{}, W4_N(18), W4_N(13), T_{}, 13);
+      run_step(C0{}, F_{}, W4_N(18), W4_N(14), T_{}, 14);
+      run_step(C1{}, F_{}, W4_N(18), W4_N(15), T_{}, 15);
+      run_step(C0{}, F_{}, W4_N(18), W4_N(-1), T_{}, 16);
+      run_step(C1{}, F_{}, W4_N(17), W4_N(-1), T_{}, 17);
     } else {
-      run_step(C0{}, T_{}, W4_N(16), W4_N(-1), T_{}, 0);
-      run_step(C1{}, F_{}, W4_N(16), W4_N(-1), T_{}, 1);
-      for (int hs = 2; hs < 10; hs += 2) {
-        run_step(C0{}, F_{}, W4_N(16), W4_N(-1), T_{}, hs);
+      for (int hs = 0; hs < 18; hs += 2) {
+        if (hs == 0) run_step(C0{}, T_{}, W4_N(16), W4_N(-1), T_{}, 0);
+        else run_step(C0{}, F_{}, W4_N(16), W4_N(-1), T_{}, hs);
         run_step(C1{}, F_{}, W4_N(16), W4_N(-1), T_{}, hs + 1);
       }
     }
-    for (int hs = 10; hs < nhs - 2; hs += 2) {    // host: nhs >= 12
+    for (int hs = 18; hs < nhs - 2; hs += 2) {    // host: nhs >= 20
       run_step(C0{}, F_{}, W4_N(16), W4_N(-1), T_{}, hs);
       run_step(C1{}, F_{}, W4_N(16), W4_N(-1), T_{}, hs + 1);
     }
@@ -1787,7 +1792,7 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   const bool persist = persist_ok && sizeof(TOut) == 2 && p.split_k == 1 && nhs_total >= 4 && (int)grid.x > num_cus();
   if (persist) grid.x = (unsigned)num_cus();
   p.tile_queue = nullptr;
-  if (persist && nhs_total >= 12) {
+  if (persist && nhs_total >= 20) {
     // MDT_GEMM_W4: 0 off; 1 every persistent launch; 2 the launches it is measured faster on (k-contiguous operands, light
     // epilogues: plain, bias, residual, bias + dropout + residual, saved derivative + column sums — not the GELU form, not k-major operands)
     const int w4 = sw.gemm_w4;
