@@ -394,6 +394,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
 // GEMMs against 1.05-1.13 on the same shapes without).
 // PEND: the outputs of row tiles 4-7 are not stored but handed back packed (pend[(i - 4) * NJP + jp], 16 bytes per lane each):
 // the 4-wave kernel keeps them in registers and lets them leave during the next tile's first steps.
+#ifndef MDT_W4_PEND_ROWS
+#define MDT_W4_PEND_ROWS 4
+#endif
+constexpr int EPI_PEND_ROWS = MDT_W4_PEND_ROWS;          // PEND epilogues: the last EPI_PEND_ROWS row tiles are handed back, not stored
 // What a compile-time epilogue reads before it can start — the bias vectors of the wave's columns and the first column pair's
 // residual / saved-derivative vectors — requested ahead (EPF: the 4-wave kernel asks for them before its last 32-k step, whose
 // free fragment registers hold them: at the epilogue they have long arrived, and the wait in front of their first use
@@ -599,7 +603,7 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
       if constexpr (PEND) {
-        if constexpr (i >= 4) pend[(i - 4) * NJP + jp] = o;
+        if constexpr (i >= 8 - EPI_PEND_ROWS) pend[(i - (8 - EPI_PEND_ROWS)) * NJP + jp] = o;
         else epi_store16(__builtin_bit_cast(i32x4, o), eb->rsC, eb->voffC, i * eb->ldc16 + jp * 64);
         break;
       }
@@ -1264,6 +1268,17 @@ __device__ __forceinline__ void w4_dma(__amdgpu_buffer_rsrc_t rs, char* lds, uns
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds), 16, voff, soff, 0, 0);
 }
 
+constexpr int W4_PEND_ROWS = MDT_W4_PEND_ROWS;          // row tiles (of a wave's eight) whose outputs wait in registers
+constexpr int W4_NPEND = 4 * W4_PEND_ROWS;              // ... = pending 16-byte vectors per lane, one leaves per step
+constexpr int W4_NEXPL = W4_NPEND + 2;                  // explicit steps of a tile (compile-time vmcnt budget and pending index)
+// operations a wave issues in step s of a tile (8 LDS-DMA pieces + the pending store); steps before the tile: 8
+constexpr int w4_ops(int s) { return 8 + (s >= 0 && s < W4_NPEND ? 1 : 0); }
+// what may be in flight at the start of step s while the pieces of step s + 1 (requested in step s - 3) must have landed:
+// the operations of steps s - 2 and s - 1, and in a tile's first three steps the epilogue's direct stores issued in between
+constexpr int w4_budget(int s) { return w4_ops(s - 2) + w4_ops(s - 1) + (s < 3 ? 32 - W4_NPEND : 0); }
+template <class F, int... S>
+__device__ __forceinline__ void w4_unroll(F&& f, std::integer_sequence<int, S...>) { (f(std::integral_constant<int, S>{}), ...); }
+
 template <bool A_KM, bool B_KM, int EPK = -1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w4p(GemmParams p) {
   constexpr int PP_DIST = 4, PP_NB = 5;
@@ -1391,15 +1406,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   int b_next = 1, b_wr = PP_DIST % PP_NB;
   f32x4 acc[8][8];
-  constexpr int W4_DS = 16;                        // direct stores of an epilogue (row tiles 0-3 x 4 column pairs): a constant, see EpiBuf
+  constexpr int W4_DS = 32 - W4_NPEND;             // direct stores of an epilogue (the other row tiles x 4 column pairs): a constant, see EpiBuf
 
   // Pending outputs: row tiles 4-7 of a finished tile stay packed in registers (16 vectors of 16 bytes per lane) and
   // leave one per step during steps 0-15 of the next tile, through a buffer descriptor based at the tile's origin (rows past
   // M fall outside it and are dropped).  The other half is stored at the tile's end as before: the burst is half as long.
   constexpr bool PEND = EPK >= 0;                  // the specialised epilogues (the runtime-flag kernel keeps the plain form)
-  bf16x8 pend[16];
+  bf16x8 pend[W4_NPEND];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) pend[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < W4_NPEND; ++i) pend[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, 0, 0x00020000);
   const int c_lane = lane & 15, g_lane = lane >> 4;
   const unsigned voffP = (unsigned)((wr * 128 + c_lane) * (p.ldc * 2) + (wc * 128 + 16 * (g_lane & 1) + 8 * (g_lane >> 1)) * 2);
@@ -1445,8 +1460,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       W4_MF(b, 4); W4_MF(b, 5);
       issue_piece(d_issue, sa, sb, b_wr, b);
       if constexpr (ST >= 0) {
-        if (b == 4) {                                // pending vector ST -> row tile 4 + ST / 4, column pair ST % 4
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, pend[ST]), rsP, voffP, (4 + (ST >> 2)) * ldc16 + (ST & 3) * 64, 0);
+        if (b == 4) {                                // pending vector ST -> row tile (8 - W4_PEND_ROWS) + ST / 4, column pair ST % 4
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, pend[ST]), rsP, voffP,
+                                                 (8 - W4_PEND_ROWS + (ST >> 2)) * ldc16 + (ST & 3) * 64, 0);
         }
       }
       W4_MF(b, 6); W4_MF(b, 7);
@@ -1480,32 +1496,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // its code: the compiler parked registers in scratch around it and, where the two paths met, drained the whole prefetch ring
     // (s_waitcnt vmcnt(0)) once per TILE.
     if constexpr (PEND) {
-      run_step(C0{}, T_{}, W4_N(16 + W4_DS), W4_N(0), T_{}, 0);
-      run_step(C1{}, F_{}, W4_N(17 + W4_DS), W4_N(1), T_{}, 1);
-      run_step(C0{}, F_{}, W4_N(18 + W4_DS), W4_N(2), T_{}, 2);
-      run_step(C1{}, F_{}, W4_N(18), W4_N(3), T_{}, 3);
-      run_step(C0{}, F_{}, W4_N(18), W4_N(4), T_{}, 4);
-      run_step(C1{}, F_{}, W4_N(18), W4_N(5), T_{}, 5);
-      run_step(C0{}, F_{}, W4_N(18), W4_N(6), T_{}, 6);
-      run_step(C1{}, F_{}, W4_N(18), W4_N(7), T_{}, 7);
-      run_step(C0{}, F_{}, W4_N(18), W4_N(8), T_{}, 8);
-      run_step(C1{}, F_{}, W4_N(18), W4_N(9), T_{}, 9);
-      run_step(C0{}, F_{}, W4_N(18), W4_N(10), T_{}, 10);
-      run_step(C1{}, F_{}, W4_N(18), W4_N(11), T_{}, 11);
-      run_step(C0{}, F_{}, W4_N(18), W4_N(12), T_{}, 12);
-      run_step(C1{}, F_{}, W4_N(18), W4_N(13), T_{}, 13);
-      run_step(C0{}, F_{}, W4_N(18), W4_N(14), T_{}, 14);
-      run_step(C1{}, F_{}, W4_N(18), W4_N(15), T_{}, 15);
-      run_step(C0{}, F_{}, W4_N(18), W4_N(-1), T_{}, 16);
-      run_step(C1{}, F_{}, W4_N(17), W4_N(-1), T_{}, 17);
+      w4_unroll([&](auto sc) __attribute__((always_inline)) {
+        constexpr int S = decltype(sc)::value;
+        run_step(std::integral_constant<int, S & 1>{}, std::integral_constant<bool, S == 0>{}, W4_N(w4_budget(S)),
+                 W4_N(S < W4_NPEND ? S : -1), T_{}, S);
+      }, std::make_integer_sequence<int, W4_NEXPL>{});
     } else {
-      for (int hs = 0; hs < 18; hs += 2) {
+      for (int hs = 0; hs < W4_NEXPL; hs += 2) {
         if (hs == 0) run_step(C0{}, T_{}, W4_N(16), W4_N(-1), T_{}, 0);
         else run_step(C0{}, F_{}, W4_N(16), W4_N(-1), T_{}, hs);
         run_step(C1{}, F_{}, W4_N(16), W4_N(-1), T_{}, hs + 1);
       }
     }
-    for (int hs = 18; hs < nhs - 2; hs += 2) {    // host: nhs >= 20
+    for (int hs = W4_NEXPL; hs < nhs - 2; hs += 2) {    // host: nhs >= W4_NEXPL + 2
       run_step(C0{}, F_{}, W4_N(16), W4_N(-1), T_{}, hs);
       run_step(C1{}, F_{}, W4_N(16), W4_N(-1), T_{}, hs + 1);
     }
@@ -1561,8 +1564,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       else {                                      // nothing follows: the pending half leaves now
         const __amdgpu_buffer_rsrc_t rl = eb.rsC;
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, pend[idx]), rl, voffP, (4 + (idx >> 2)) * ldc16 + (idx & 3) * 64, 0);
+        for (int idx = 0; idx < W4_NPEND; ++idx)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, pend[idx]), rl, voffP,
+                                                 (8 - W4_PEND_ROWS + (idx >> 2)) * ldc16 + (idx & 3) * 64, 0);
       }
     }
     if (!has_next) break;
@@ -1792,7 +1796,7 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   const bool persist = persist_ok && sizeof(TOut) == 2 && p.split_k == 1 && nhs_total >= 4 && (int)grid.x > num_cus();
   if (persist) grid.x = (unsigned)num_cus();
   p.tile_queue = nullptr;
-  if (persist && nhs_total >= 20) {
+  if (persist && nhs_total >= W4_NEXPL + 2) {
     // MDT_GEMM_W4: 0 off; 1 every persistent launch; 2 the launches it is measured faster on (k-contiguous operands, light
     // epilogues: plain, bias, residual, bias + dropout + residual, saved derivative + column sums — not the GELU form, not k-major operands)
     const int w4 = sw.gemm_w4;
