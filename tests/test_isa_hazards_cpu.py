@@ -1,0 +1,127 @@
+"""Static checks on the gfx950 assembly of the 4-wave GEMM kernel (gemm_bf16_w4p): its MFMAs are asm statements, which hides
+them from the compiler's hazard recognizer, and three things that went wrong on the GPU because of that are visible in the
+instruction stream ("three traps").  The checks read the disassembly of the object the in-tree build produced (no GPU needed).
+
+  1. no accumulator read (v_accvgpr_read) inside or right behind the MFMA stream of a step;
+  2. no 16-byte buffer store whose data registers are rewritten by the next instructions (hipcc does not protect MUBUF
+     stores with an SGPR offset);
+  3. no s_waitcnt vmcnt(0) and no scratch traffic between the first and the last workgroup barrier of a tile's K loop
+     (either one drains the LDS-DMA prefetch ring);
+  4. the specialised instantiations with light epilogues use no scratch at all.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+@pytest.fixture(scope="module")
+def w4_kernels(tmp_path_factory):
+    """(instruction lists, scratch bytes) of every gemm_bf16_w4p instantiation, disassembled from the object the build made"""
+    if not (os.path.exists(OBJDUMP) and os.path.exists(READELF)):
+        pytest.skip("llvm-objdump / llvm-readelf not available")
+    from multimodaldiscussiontransformer_amd import build as B
+    B.build()                                           # no-op when the objects are newer than the sources
+    tmp = tmp_path_factory.mktemp("isa")
+    obj = shutil.copy(os.path.join(B.HERE, "build", "gemm.o"), tmp / "gemm.o")
+    subprocess.run([OBJDUMP, "--offloading", str(obj)], cwd=tmp, capture_output=True, text=True, check=True)   # unbundles beside it
+    co = [f for f in os.listdir(tmp) if "amdgcn" in f]
+    assert len(co) == 1, os.listdir(tmp)
+    co = str(tmp / co[0])
+    dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout.split("\n")
+    kernels, cur = {}, None
+    for l in dis:
+        m = re.match(r"^[0-9a-f]+ <(\w+)>:", l)
+        if m:
+            cur = kernels.setdefault(m.group(1), []) if "gemm_bf16_w4p" in m.group(1) else None
+            continue
+        if cur is not None:
+            t = l.split("//")[0].strip()
+            if t:
+                cur.append(t)
+    assert len(kernels) >= 10, sorted(kernels)
+    notes = subprocess.run([READELF, "--notes", co], capture_output=True, text=True, check=True).stdout
+    scratch = {}
+    for blk in re.split(r"\n\s+- \.", notes):
+        n = re.search(r"\.name:\s+(\S+)", blk) or re.search(r"^name:\s+(\S+)", blk, re.M)
+        ps = re.search(r"private_segment_fixed_size:\s+(\d+)", blk)
+        if n and ps:
+            scratch[n.group(1)] = int(ps.group(1))
+    return kernels, scratch
+
+
+def _specialised(name):
+    m = re.search(r"ILb[01]ELb[01]ELi(\d+)E", name)      # "Lin1E" = -1 is the runtime-flag kernel
+    return int(m.group(1)) if m else None
+
+
+def _vregs(tok):
+    r = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if r:
+        return set(range(int(r.group(1)), int(r.group(2)) + 1))
+    r = re.match(r"v(\d+)$", tok)
+    return {int(r.group(1))} if r else set()
+
+
+def test_no_accumulator_read_in_the_mfma_stream(w4_kernels):
+    kernels, _ = w4_kernels
+    for name, body in kernels.items():
+        for i, t in enumerate(body):
+            if not t.startswith("v_accvgpr_read"):
+                continue
+            if any(x.startswith("v_mfma") for x in body[i:i + 12]):
+                pytest.fail(f"{name}: {t} within the MFMA stream (instruction {i})")
+            for k in range(i - 1, max(0, i - 8), -1):            # an MFMA shortly before: the wait states in between
+                if body[k].startswith("v_mfma"):
+                    ws = sum(int(x.split()[1]) + 1 for x in body[k + 1:i] if x.startswith("s_nop"))
+                    assert ws >= 12, f"{name}: {t} only {ws} wait states behind {body[k]}"
+                    break
+
+
+def test_store_data_registers_are_not_rewritten_behind_the_store(w4_kernels):
+    kernels, _ = w4_kernels
+    for name, body in kernels.items():
+        for i, t in enumerate(body):
+            m = re.match(r"buffer_store_dwordx4 (v\[\d+:\d+\])", t)
+            if not m:
+                continue
+            data = _vregs(m.group(1))
+            for nxt in body[i + 1:i + 3]:
+                if nxt.startswith("s_nop"):
+                    break
+                mm = re.match(r"v_\w+\s+(v\d+|v\[\d+:\d+\])", nxt)
+                if mm and _vregs(mm.group(1)) & data and not nxt.startswith(("v_cmp", "v_cmpx")):
+                    pytest.fail(f"{name}: '{nxt}' rewrites the data of '{t}' without wait states")
+
+
+def test_nothing_drains_the_prefetch_ring_inside_the_k_loop(w4_kernels):
+    kernels, _ = w4_kernels
+    for name, body in kernels.items():
+        if _specialised(name) in (None, 259):      # runtime-flag kernel; fc1 forward (GELU) is not launched on this kernel by default
+            continue
+        bars = [i for i, t in enumerate(body) if t == "s_barrier"]
+        assert len(bars) > 10, name
+        lo, hi = bars[1], bars[-1]             # bars[0] is the prologue's; the last one opens the tile's last step
+        for i in range(lo, hi):
+            t = body[i]
+            assert not t.startswith("scratch_"), f"{name}: {t} inside the K loop (instruction {i})"
+            assert "vmcnt(0)" not in t, f"{name}: {t} inside the K loop (instruction {i})"
+
+
+def test_light_epilogues_use_no_scratch(w4_kernels):
+    _, scratch = w4_kernels
+    light = {0, 1, 4, 69}                      # plain, bias, residual, bias + dropout + residual
+    seen = 0
+    for name, b in scratch.items():
+        if "gemm_bf16_w4p" in name and _specialised(name) in light:
+            seen += 1
+            assert b == 0, f"{name}: {b} bytes of scratch per lane"
+    assert seen >= 6
