@@ -426,8 +426,10 @@ __device__ __forceinline__ void epi_prefetch(const GemmParams& p, int lane, int6
   constexpr int PRE_KIND = epi_pre_kind<EPK>();
   const int64_t gc0 = n0w + 16 * (g & 1) + 8 * (g >> 1);
   if constexpr (EPK >= 0 && (EPK & MDT_EPI_BIAS) != 0) {
+    const bf16_t* bb = (const bf16_t*)p.bias + n0w;                  // uniform base + 32-bit lane offset (no 64-bit lane address to hoist)
+    const int lc = 16 * (g & 1) + 8 * (g >> 1);
 #pragma unroll
-    for (int jp = 0; jp < NJP; ++jp) f.bias[jp] = *(const bf16x8*)((const bf16_t*)p.bias + gc0 + 32 * jp);
+    for (int jp = 0; jp < NJP; ++jp) f.bias[jp] = *(const bf16x8*)(bb + (lc + 32 * jp));
   }
   if constexpr (PRE_KIND != 0) {
     const bf16_t* base = PRE_KIND == 1 ? (const bf16_t*)p.aux : PRE_KIND == 2 ? (const bf16_t*)p.residual : (const bf16_t*)p.C;
@@ -497,7 +499,7 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
   };
   const int64_t rows_left64 = p.M - m0w;           // uniform over the wave
   const int rows_left = rows_left64 > 0x40000000 ? 0x40000000 : (int)rows_left64;
-  bf16x8 pre[8];
+  bf16x8 pre[8];      // (two column pairs in flight instead of one — 32 more registers, there is room — gain nothing: measured)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     if constexpr (EPF && PRE_KIND != 0) pre[i] = pf->pre[i];
