@@ -1372,6 +1372,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int steps = (blockIdx.x & 7) * ((nhs + 12) / 8);
     for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(28);
   }
+  if (p.epilogue & (1 << 28)) {   // diagnostic (MDT_GEMM_DIAG=256): inside an XCD, skew the groups of workgroups that share an A row panel
+    const int groups = 32 / p.group_n;                              // meant for group_n = tiles_n dividing 32 (N = 1024: 8 groups of 4)
+    const int steps = (((int)blockIdx.x >> 3) / p.group_n) * ((nhs + 12) / (groups > 0 ? groups : 1));
+    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(28);
+  }
   int v = blockIdx.x;
   int v_next = v + (int)gridDim.x < nvt ? v + (int)gridDim.x : -1;
   Desc cur = make_desc(v);
@@ -2081,7 +2086,7 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   p.tile_queue = nullptr;
   p.alpha_dev = p.alpha_dev2 = nullptr;
   p.group_n = 1 << 30;   // row-major unless launch_pp256 decides otherwise
-  p.epilogue |= switches().gemm_diag << 20;   // diagnostics: 1 skip stores, 2 sc1 stores, 4 skewed starts within an XCD, 8 every tile loads tile (0,0)'s panels, 64 XCDs skewed against each other
+  p.epilogue |= switches().gemm_diag << 20;   // diagnostics: 1 skip stores, 2 sc1 stores, 4 skewed starts within an XCD, 8 every tile loads tile (0,0)'s panels, 64 XCDs skewed against each other, 256 row-panel groups skewed inside an XCD (4-wave kernel)
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_COLSUM) || (colsum && split_k == 1), "mdt_gemm: MDT_EPI_COLSUM needs a colsum buffer and split_k == 1");
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_ASUM) || (colsum && trans_a && (epilogue & MDT_EPI_ATOMIC) && !(epilogue & MDT_EPI_COLSUM) && dtype == MDT_BF16),
                 "mdt_gemm: MDT_EPI_ASUM needs bf16 operands, trans_a = 1, MDT_EPI_ATOMIC, a colsum buffer and no MDT_EPI_COLSUM");

@@ -62,6 +62,10 @@ def combos(M):
         out.append(("NN bias+res+drop", x768, w, dict(bias=r(768), residual=r(M, 768), drop_p=0.4, drop_seed=3)))
         out.append(("NT plain", x768, wt, dict(trans_b=True)))
         out.append(("NT res", x768, wt, dict(trans_b=True, residual=r(M, 768))))
+    if "--n1024" in sys.argv:    # four column tiles: the 32 workgroups of an XCD are 8 row-panel groups of 4 (MDT_GEMM_DIAG=256)
+        out = [("NN bias N1024", x768, r(1024, 768), dict(bias=r(1024))),
+               ("NN bias+res+drop N1024", x768, r(1024, 768), dict(bias=r(1024), residual=r(M, 1024), drop_p=0.4, drop_seed=3)),
+               ("NN plain N1024 K3072", x3072, r(1024, 3072), dict())]
     if "--nn-dgrad" in sys.argv:   # the input-gradient launches against a pre-transposed weight copy (k-contiguous B) beside the k-major form
         out = []
         for (nm, xin, n_out, k_in, extra) in [("dqkv plain", x2304, 768, 2304, {}), ("do plain", x768, 768, 768, {}),
