@@ -170,6 +170,33 @@ def test_gemm_four_wave_form_is_bit_identical(ops, tb, kind, monkeypatch):
         torch.testing.assert_close(outs[1].float(), ref, atol=0.5, rtol=2e-2)
 
 
+@pytest.mark.parametrize("K", [576, 640, 704, 1088])
+def test_gemm_four_wave_form_short_and_odd_k(ops, K, monkeypatch):
+    """The 4-wave kernel walks 18 explicit steps, a loop and two closing steps per tile: K = 640 is the shortest launch it takes
+    (20 steps, empty loop), 704 the next (22), 1088 has an odd number of 64-deep K-tiles behind the explicit steps; K = 576 must
+    stay on the 8-wave kernel even when the 4-wave one is forced.  Same bits as the 8-wave kernel everywhere."""
+    from multimodaldiscussiontransformer_amd import _lib as L
+    M, N = 33000 + 5, 512
+    bf = torch.bfloat16
+    a = dev(rnd(M, K, seed=41).to(bf))
+    for tb in (False, True):
+        b = dev((rnd(K, N, seed=42) if tb else rnd(N, K, seed=42)).to(bf))
+        kw = dict(trans_b=tb, bias=dev(rnd(N, seed=43).to(bf)), residual=dev(rnd(M, N, seed=44).to(bf)), drop_p=0.4, drop_seed=9)
+        outs = []
+        try:
+            for v in ("0", "1"):
+                monkeypatch.setenv("MDT_GEMM_W4", v)
+                L.reload_env()
+                outs.append(ops.gemm(a, b, **kw).clone())
+        finally:
+            monkeypatch.delenv("MDT_GEMM_W4")
+            L.reload_env()
+        assert torch.equal(outs[0], outs[1])
+        ref = a.float() @ (b.float() if tb else b.float().t())
+        plain = ops.gemm(a, b, trans_b=tb)
+        torch.testing.assert_close(plain.float(), ref, atol=0.6, rtol=2e-2)
+
+
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_gemm_bf16_tile256_pipeline(ops, ta, tb):
     """Shapes large enough for the 256x128 three-stage kernel (>= 256 tiles), ragged M tail,
