@@ -422,6 +422,13 @@ __device__ __forceinline__ void epi_store16(i32x4 v, __amdgpu_buffer_rsrc_t rs, 
 }
 template <int NJP, int EPK, bool PEND = false>
 __device__ __forceinline__ void epi_prefetch(const GemmParams& p, int lane, int64_t m0w, int64_t n0w, EpiPre<NJP>& f, const EpiBuf* eb = nullptr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (PEND) {       // lane-derived address parts are recomputed per tile, not carried through the K loop (see direct_epilogue)
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z));
+  }
+#endif
   const int c = lane & 15, g = lane >> 4;
   constexpr int PRE_KIND = epi_pre_kind<EPK>();
   const int64_t gc0 = n0w + 16 * (g & 1) + 8 * (g >> 1);
