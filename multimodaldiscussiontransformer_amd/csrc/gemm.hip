@@ -1831,6 +1831,7 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
         if (p.tiles_n % 2 == 0 && b_panel * p.tiles_n > 3.5e6 && b_panel * (p.tiles_n / 2) <= 2.5e6 && (double)p.tiles_m * p.tiles_n >= 4.0 * num_cus())
           p.group_n = p.tiles_n / 2;
       }
+      if (sw.gemm_group >= 1) p.group_n = sw.gemm_group < p.tiles_n ? sw.gemm_group : p.tiles_n;   // MDT_GEMM_GROUP: A/B runs
       const size_t lds = (size_t)5 * PP_STAGE;
 #define LW4(A_, B_, E_)                                                                                      \
   {                                                                                                          \
