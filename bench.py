@@ -81,6 +81,41 @@ def base_args(a):
         vit_config=dict(dim=c["dim"], layers=c["layers"], heads=c["heads"], intermediate=c["ffn"], image_size=c["image"], patch=c["patch"]))
 
 
+def trees_for_rank(step: int, rank: int, world: int, *, trees_per_gpu: int, nodes: int, image_frac: float, image_size: int, patch: int,
+                   shape: str, variable: bool = False, image_pool=None):
+    """Host trees rank ``rank`` of ``world`` processes in step ``step`` (weak scaling, BASELINE.json configs[1] / [2]):
+    the global batch is ``trees_per_gpu * world`` trees from ONE seeded stream, every rank generates all of it and keeps
+    its share, dealt by token cost (ddp.balance_trees).  Default = the SAME fixed ``nodes``-comment trees
+    at every N — configs[2] is "global batch 256 trees" of 64 comments = 32 per GPU — so the driver's N = 1, 2, 4, 8
+    lines measure one per-GPU workload; with equal trees the deal degenerates to equal counts.  ``variable`` (bench.py
+    --variable-trees) draws tree sizes U{nodes/2..nodes} instead: the load-balancing demonstration, NOT comparable with
+    the N = 1 line."""
+    from multimodaldiscussiontransformer_amd import synthetic
+    from multimodaldiscussiontransformer_amd.ddp import balance_trees
+    kw = dict(seq_len=100, image_frac=image_frac, image_size=image_size, shape=shape, image_pool=image_pool)
+    if world == 1 and not variable:
+        return synthetic.make_trees(trees_per_gpu, nodes, seed=1234 + step, **kw)
+    glob = synthetic.make_trees(trees_per_gpu * world, nodes, seed=1234 + step, variable=variable, **kw)
+    share = balance_trees([len(t["parent"]) for t in glob], [int(t["image_index"].sum()) for t in glob], world,
+                          text_tokens=100 + 4, image_tokens=(image_size // patch) ** 2 + 1 + 4)
+    return [glob[j] for j in share[rank]]
+
+
+def code_state_hash() -> str:
+    """sha256 (16 hex digits) over the kernel sources and the host modules that decide which kernels run — the identity of
+    "the code a profile was taken on" (tools/save_profile.py stores it next to every PMC pass; the bench line refuses
+    traffic numbers from another code state)."""
+    import hashlib
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, "multimodaldiscussiontransformer_amd")
+    files = sorted(os.path.join(pkg, "csrc", f) for f in os.listdir(os.path.join(pkg, "csrc")))
+    files += [os.path.join(pkg, f) for f in ("engine.py", "ops.py", "build.py")] + [os.path.join(ROOT, "include", "mdt_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def flops_per_comment(L=100, nb=4, P=197, D=768, F=3072, Lb=6, Lf=6, G=6, N=64, Fg=768, rho=0.25, patch=16, lens=None,
                       prune_last=False):
     """Algorithmic forward FLOPs per comment.  ``lens``: valid-token counts of the comments when the
@@ -408,6 +443,10 @@ def main():
     ap.add_argument("--no-selfcheck", action="store_true", help="skip the numerics guard that runs before the warm-up")
     ap.add_argument("--resident-batches", action="store_true",
                     help="round-1 behaviour: alternate two pre-packed HBM-resident batches instead of streaming fresh ones")
+    ap.add_argument("--variable-trees", action="store_true",
+                    help="tree sizes U{nodes/2..nodes} dealt to the ranks by token cost (the balancing demonstration; the default is the "
+                         "same fixed trees at every N, so that the N = 1, 2, 4, 8 lines measure one per-GPU workload)")
+    ap.add_argument("--no-verify-exchange", action="store_true", help="N > 1: skip the gradient-exchange self-check after the timed region")
     ap.add_argument("--with-optimizer", action="store_true",
                     help="also run the fused Adam update inside every timed step (the headline metric is fwd+bwd only)")
     args = ap.parse_args()
@@ -470,7 +509,8 @@ def main():
 
     # ---- synthetic trees (host arrays), generated BEFORE anything is timed.  Every step gets its own batch; image
     # pixels are windows (views) of one shared pool of random images at per-tree random offsets, so that the host holds
-    # one pool instead of 308 MB per batch.  With N > 1 the global batch of a step is dealt to the ranks by token cost.
+    # one pool instead of 308 MB per batch.  With N > 1 the global batch of a step is dealt to the ranks by token cost
+    # (trees_for_rank: the same fixed trees at every N unless --variable-trees).
     n_roof = max(1, min(args.steps, 4))
     n_stream = args.warmup + args.steps + 1
     per_tree_img = int(round(args.image_frac * args.nodes))
@@ -478,15 +518,8 @@ def main():
     pool = rng_pool.standard_normal((max(per_tree_img * 6, 1) + 64, 3, cfg["image"], cfg["image"]), dtype=np.float32) if per_tree_img else None
 
     def trees_of_step(i):
-        kw = dict(seq_len=100, image_frac=args.image_frac, image_size=cfg["image"], shape=cfg["shape"], image_pool=pool)
-        if world == 1:
-            return synthetic.make_trees(args.trees, args.nodes, seed=1234 + i, **kw)
-        # the same global batch on every rank (seeded), each rank keeps its share: greedy token-cost balancing (§8e)
-        glob = synthetic.make_trees(args.trees * world, args.nodes, seed=1234 + i, variable=True, **kw)
-        nb_, Lq, P_ = 4, 100, (cfg["image"] // cfg["patch"]) ** 2 + 1
-        share = balance_trees([len(t["parent"]) for t in glob], [int(t["image_index"].sum()) for t in glob], world,
-                              text_tokens=Lq + nb_, image_tokens=P_ + nb_)
-        return [glob[j] for j in share[rank]]
+        return trees_for_rank(i, rank, world, trees_per_gpu=args.trees, nodes=args.nodes, image_frac=args.image_frac, image_size=cfg["image"],
+                              patch=cfg["patch"], shape=cfg["shape"], variable=args.variable_trees, image_pool=pool)
 
     t_gen = time.perf_counter()
     n_distinct = 2 if args.resident_batches else n_stream
@@ -557,6 +590,7 @@ def main():
         ev[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
+    dist_diag = dp.diagnostics() if dp.bucketer.active else None        # of the LAST TIMED step (before the check runs below change it)
     step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
     ms_median = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     # host time to ENQUEUE one step (no sync inside a step), taken on an idle GPU: inside the back-to-back timed region
@@ -589,6 +623,20 @@ def main():
         dt_single = (time.perf_counter() - t1) / n_roof
         timer.enabled = False
         ge_.two_streams = two
+    # N > 1 (or MDT_DDP_FORCE=1): the exchange checks itself once, outside every timed region — replicas bit-equal after a
+    # bucketed, overlapped step; that step against the same step with every bucket held back until backward has ended,
+    # and against ONE flat all-reduce of the arena (same batch, same dropout seeds: ddp.DataParallel.verify_exchange)
+    exchange_check = None
+    if dp.bucketer.active and not args.no_verify_exchange:
+        vb = last
+
+        def same_step():
+            torch.manual_seed(4242)                 # dropout-site seeds come from the CPU generator (engine.Tape.next_seed)
+            step(vb)
+            torch.cuda.synchronize()
+        exchange_check = dp.verify_exchange(same_step)
+        if not exchange_check["ok"]:
+            raise SystemExit(f"gradient exchange self-check failed on rank {rank}: {exchange_check}")
     tot = torch.tensor([dt, float(sum(comments))], dtype=torch.float64, device="cuda")
     if dist.is_initialized():
         both = [torch.zeros_like(tot) for _ in range(world)]
@@ -613,21 +661,28 @@ def main():
         if os.environ.get("MDT_BENCH_GEMM_TABLE") == "1" and gs:
             print(timer.table(), file=sys.stderr, flush=True)
         roofline = None
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_note = None, None, None
         try:                                       # HBM-side bytes per launch of the GEMM family, from the committed PMC passes
             import glob
             import re
             cand = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")),
                           key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])      # round, version: numeric order
-            if cand and args.config == "base":
-                traffic = json.load(open(cand[-1]))["gemm_family_bytes_per_launch"]
+            if cand and args.config == "base" and args.dtype == "bf16":
+                prof = json.load(open(cand[-1]))
                 traffic_src = "profiles/" + os.path.basename(cand[-1])
+                # a PMC pass describes the code it was taken on: tools/save_profile.py stores code_state_hash() beside the
+                # numbers, and a profile from another code state (or from before the hash existed) is not quoted
+                if prof.get("code_state_hash") == code_state_hash():
+                    traffic = prof["gemm_family_bytes_per_launch"]
+                else:
+                    traffic_note = (f"null: the newest committed PMC pass ({traffic_src}) was taken on code state {prof.get('code_state_hash')}, "
+                                    f"this run is {code_state_hash()} — re-run tools/run_profile.sh")
         except (OSError, KeyError, ValueError):
             pass
         if gs:
             roofline = dict(bound="mfma", kernel="gemm_bf16_w4p / gemm_bf16_pp256p / gemm_bf16_pp256 (bf16 MFMA tile GEMM family: persistent 256x256 in its 4-wave and 8-wave ping-pong forms, split-K 256x256, 128x128)", achieved=round(gs["tflops"], 1),
                             peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(gs["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4),
-                            traffic=traffic, traffic_unit="bytes per launch (fabric-side FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)", traffic_source=traffic_src,
+                            traffic=traffic, traffic_unit="bytes per launch (fabric-side FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)", traffic_source=traffic_src, traffic_note=traffic_note, code_state_hash=code_state_hash(),
                             algorithmic_bytes_per_launch=round(gs["bytes"] / gs["launches"]) if gs.get("bytes") else None, launches=gs["launches"], avg_launch_us=round(gs["avg_us"], 1),
                             share_of_step=round(gs["total_ms"] * 1e-3 / (dt_single * n_roof), 3),
                             measured=f"HIP events around every launch in a separate pass of {n_roof} steps on one HIP stream right after the "
@@ -663,8 +718,9 @@ def main():
         if fp8_state is not None:
             out["fp8"] = dict(gemm_launches_total=fp8_state.gemms, sites=len(fp8_state.sites), formats="e4m3 activations / weights, e5m2 gradients",
                               scaling="per tensor, delayed (margin 2), device-resident", where="qkv fwd, fc1 fwd, fc2 input gradient")
-        if world > 1:
-            out["distributed"] = dict(world=world, backend=backend, comments_per_rank=per_rank_comments, **dp.diagnostics())
+        if dist_diag is not None:
+            out["distributed"] = dict(world=world, backend=backend, comments_per_rank=per_rank_comments, variable_trees=bool(args.variable_trees),
+                                      exchange_check=exchange_check, **dist_diag)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

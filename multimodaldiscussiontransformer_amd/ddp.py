@@ -52,6 +52,9 @@ class GradientBucketer:
         # half-precision gradients too) that is summed by RCCL and added back into the fp32 arena
         self.wire_dtype = wire_dtype if wire_dtype not in (None, torch.float32) else None
         self.bucket_events = []
+        self.backward_end = None
+        self.last_launch_log = []
+        self.defer = False         # verification: hold every bucket back until finish() (no overlap with backward)
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.pg = process_group
         self.comm_stream = comm_stream
@@ -121,6 +124,7 @@ class GradientBucketer:
     # -- per-step state -------------------------------------------------------------------
     def reset(self):
         self._pending_wire = []
+        self.launch_log = []       # (start, end) element ranges in the order they were handed to all_reduce this step
         self.ready = [False] * len(self.slots)
         self.cursor = 0            # slots [0, cursor) are final
         self.launched = 0          # elements [0, launched) already handed to all_reduce
@@ -140,7 +144,7 @@ class GradientBucketer:
             self.ready[i] = True
         while self.cursor < len(self.slots) and self.ready[self.cursor]:
             self.cursor += 1
-        if self.active and self.layout_final:
+        if self.active and self.layout_final and not self.defer:
             # launch every static bucket that is now entirely final — the SEQUENCE of collectives (sizes and
             # order) is fixed by bucket_ends, only its timing depends on this rank's batch
             end = self.slots[self.cursor - 1][1] + self.slots[self.cursor - 1][2] if self.cursor else 0
@@ -148,14 +152,39 @@ class GradientBucketer:
                 self._launch(self.launched, self.bucket_ends[self.next_bucket])
                 self.next_bucket += 1
 
+    def _backend_is_stream_ordered(self) -> bool:
+        """RCCL / NCCL work handles are stream-ordered: ``wait()`` returns at once on the host and makes the CURRENT stream
+        wait for the collective.  gloo's ``wait()`` blocks the host until the result is there."""
+        if getattr(self, "_stream_ordered", None) is None:
+            try:
+                self._stream_ordered = dist.is_initialized() and "nccl" in str(dist.get_backend(self.pg)).lower()
+            except (RuntimeError, ValueError):
+                self._stream_ordered = False
+        return self._stream_ordered
+
     def _reduce(self, chunk: torch.Tensor):
+        """One bucket.  Called with the comm stream current (GPU) or plainly (CPU / gloo).  On a stream-ordered backend the
+        handle is waited for right here — that only orders the COMM stream behind RCCL's internal stream, the host goes
+        on issuing backward — so everything enqueued on the comm stream afterwards (the bf16 copy-back below, the
+        bucket's closing event, finally the compute stream's ``wait_stream``) sees the reduced bytes.  (Round 2 waited
+        with the compute stream current and then copied on the comm stream, which had never been ordered behind the
+        collective: a race gloo's blocking wait could not show.)"""
+        ordered = self.comm_stream is not None and self._backend_is_stream_ordered()
         if self.wire_dtype is None:
-            self.handles.append(dist.all_reduce(chunk, group=self.pg, async_op=True))
+            h = dist.all_reduce(chunk, group=self.pg, async_op=True)
+            if ordered:
+                h.wait()
+            else:
+                self.handles.append(h)
             return
         wire = chunk.to(self.wire_dtype)
         h = dist.all_reduce(wire, group=self.pg, async_op=True)
-        self.handles.append(h)
-        self._pending_wire.append((h, chunk, wire))
+        if ordered:
+            h.wait()
+            chunk.copy_(wire)
+        else:
+            self.handles.append(h)
+            self._pending_wire.append((h, chunk, wire))
 
     def _launch(self, a: int, b: int):
         if b <= a:
@@ -167,17 +196,21 @@ class GradientBucketer:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 self._reduce(chunk)
-                e1.record()
+                e1.record()           # stream-ordered backend: behind the collective (and the copy-back); gloo: behind its issue
                 self.bucket_events.append((e0, e1, (b - a) * 4))
         else:
             self._reduce(chunk)
         self.launched = b
+        self.launch_log.append((a, b))
 
     def finish(self, scalars: Optional[torch.Tensor] = None, sample_size_index: int = 1):
         """End of backward: reduce what is left, wait, scale by 1 / global sample size.
         ``scalars`` (fp32 vector: loss, sample_size, counters...) is summed over ranks in place."""
         if self.active:
             self.bucket_events = self.bucket_events[-64:]
+            if self.comm_stream is not None:
+                self.backward_end = torch.cuda.Event(enable_timing=True)
+                self.backward_end.record()                          # on the compute stream: where backward's kernels end
             if self.layout_final:
                 while self.next_bucket < len(self.bucket_ends):     # buckets whose parameters never reported
                     self._launch(self.launched, self.bucket_ends[self.next_bucket])
@@ -185,20 +218,19 @@ class GradientBucketer:
             else:
                 self._launch(0, self.flat.numel())                  # first step: one all-reduce of the whole arena
             if scalars is not None:
-                self.handles.append(dist.all_reduce(scalars, group=self.pg, async_op=True) if self.comm_stream is None
-                                    else self._scalar_reduce(scalars))
+                if self.comm_stream is None:
+                    self.handles.append(dist.all_reduce(scalars, group=self.pg, async_op=True))
+                else:
+                    self._scalar_reduce(scalars)
             for h in self.handles:
                 h.wait()
-            for _, chunk, wire in self._pending_wire:       # reduced low-precision copies back into the fp32 arena
-                if self.comm_stream is not None:
-                    with torch.cuda.stream(self.comm_stream):
-                        chunk.copy_(wire)
-                else:
-                    chunk.copy_(wire)
+            for _, chunk, wire in self._pending_wire:       # (host-blocking backends) reduced low-precision copies back into the fp32 arena
+                chunk.copy_(wire)                            # on the current stream, which the wait above has ordered
             if self.comm_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
         if scalars is not None:
             self.flat.div_(scalars[sample_size_index].clamp(min=1.0))
+        self.last_launch_log = list(self.launch_log)
         self.reset()
 
     def _comm_waits_for_compute(self):
@@ -211,7 +243,11 @@ class GradientBucketer:
     def _scalar_reduce(self, scalars):
         self._comm_waits_for_compute()
         with torch.cuda.stream(self.comm_stream):
-            return dist.all_reduce(scalars, group=self.pg, async_op=True)
+            h = dist.all_reduce(scalars, group=self.pg, async_op=True)
+            if self._backend_is_stream_ordered():
+                h.wait()
+            else:
+                self.handles.append(h)
 
 
 class DataParallel:
@@ -288,20 +324,89 @@ class DataParallel:
         from . import engine
         engine.weights_changed()          # written through .data: cached transposed copies (engine.dgrad) are stale
 
+    def replicas_checksum(self) -> dict:
+        """After a finished exchange every rank must hold the SAME bytes in its gradient arena (an all-reduce hands every
+        rank the identical sum; the scale is the same all-reduced scalar).  Position-weighted checksums of the arena and of
+        the parameters are gathered and compared exactly: two ranks that issued their buckets in a different order — which
+        sums one rank's bucket i with the other's bucket j and is invisible to each rank alone — disagree here."""
+        b = self.bucketer
+        f = b.flat.double()
+        n = f.numel()
+        w = torch.arange(n, device=f.device, dtype=torch.float64).remainder_(8191.0).add_(1.0)
+        psum = torch.zeros((), dtype=torch.float64, device=f.device)
+        for p in self.model.parameters():
+            psum += p.detach().double().sum()
+        digest = torch.stack([f.sum(), (f * w).sum(), f.abs().sum(), psum])
+        world = dist.get_world_size(b.pg) if dist.is_initialized() else 1
+        if world > 1:
+            both = [torch.zeros_like(digest) for _ in range(world)]
+            dist.all_gather(both, digest, group=b.pg)
+        else:
+            both = [digest]
+        equal = all(torch.equal(both[0], x) for x in both[1:])
+        worst = max(float((both[0] - x).abs().max()) for x in both) if world > 1 else 0.0
+        return dict(replicas_equal=bool(equal), checksum_max_abs_diff=worst, arena_abs_sum=float(both[0][2]), finite=bool(torch.isfinite(both[0]).all()))
+
+    def verify_exchange(self, run_step) -> dict:
+        """Self-check of the overlapped, bucketed exchange against the simplest thing that can be right.  ``run_step()``
+        must run one full step (zero_grad → forward → backward → finish_backward) on the SAME batch with the same seeds
+        each time it is called.  Three runs:
+          1. as configured (buckets launched from inside backward, on the comm stream);
+          2. every bucket held back until backward has finished (same sequence of collectives, no overlap) — a missing
+             stream dependency in 1 (a bucket reduced before its last gradient kernel finished) shows as a difference;
+          3. buckets held back AND the arena exchanged as ONE flat all-reduce — wrong bucket boundaries show here.
+        Dropout seeds and batch being equal, the runs differ only by the order of fp32 atomic adds inside backward."""
+        b = self.bucketer
+        out = {}
+        run_step()
+        g1 = b.flat.clone()
+        out["overlapped_launches"] = len(b.last_launch_log)
+        out.update(self.replicas_checksum())
+        b.defer = True
+        try:
+            run_step()
+            g2 = b.flat.clone()
+            ends = b.bucket_ends
+            b.bucket_ends = [b.flat.numel()]
+            try:
+                run_step()
+            finally:
+                b.bucket_ends = ends
+            g3 = b.flat
+            den = float(g3.norm()) + 1e-30
+            out["overlapped_vs_deferred_rel_l2"] = float((g1 - g2).norm()) / den
+            out["bucketed_vs_flat_rel_l2"] = float((g2 - g3).norm()) / den
+        finally:
+            b.defer = False
+        out["ok"] = bool(out["replicas_equal"] and out["finite"] and out["overlapped_vs_deferred_rel_l2"] < 1e-4 and out["bucketed_vs_flat_rel_l2"] < 1e-4)
+        return out
+
     def diagnostics(self) -> dict:
         """What the first multi-GPU run should print about itself (bench.py puts it into its JSON line)."""
         b = self.bucketer
-        ev = [(e0, e1, n) for (e0, e1, n) in b.bucket_events]
+        ends = b.bucket_ends or [b.flat.numel()]
+        ev = b.bucket_events[-len(ends):]
         times = []
-        for e0, e1, n in ev:
-            try:
+        overlap = None
+        try:
+            for e0, e1, n in ev:
                 e1.synchronize()
                 times.append(round(e0.elapsed_time(e1), 3))
-            except RuntimeError:
-                pass
-        ends = b.bucket_ends or [b.flat.numel()]
+            if ev and b.backward_end is not None and len(ev) == len(ends):
+                # the part of the exchange that backward did not hide: from the end of backward's last kernel (compute stream)
+                # to the end of the last bucket (comm stream), against the time the collectives took in all
+                exposed = max(0.0, b.backward_end.elapsed_time(ev[-1][1]))
+                span = max(1e-6, ev[0][0].elapsed_time(ev[-1][1]))
+                busy = sum(times)
+                overlap = dict(collective_ms_sum=round(busy, 3), first_launch_to_last_end_ms=round(span, 3),
+                               exposed_after_backward_ms=round(exposed, 3), overlap_frac=round(max(0.0, 1.0 - exposed / max(busy, 1e-6)), 4))
+        except RuntimeError:
+            pass
         sizes = [round((e - s) * 4 / 2 ** 20, 1) for s, e in zip([0] + ends[:-1], ends)]
+        world = dist.get_world_size(b.pg) if dist.is_initialized() else 1
+        backend = str(dist.get_backend(b.pg)) if dist.is_initialized() else None
         return dict(arena_mb=round(b.flat.numel() * 4 / 2 ** 20, 1), buckets=len(ends), bucket_mb=sizes,
                     wire_dtype=str(b.wire_dtype or torch.float32).replace("torch.", ""), layout_final=bool(b.layout_final),
-                    collective_issue_ms_recent=times[-len(ends):], steps=self._steps,
+                    world_seen_by_backend=world, backend_seen=backend, stream_ordered_waits=bool(b.comm_stream is not None and b._backend_is_stream_ordered()),
+                    bucket_allreduce_ms=times, overlap=overlap, launches_last_step=len(b.last_launch_log), steps=self._steps,
                     broadcast_calls=getattr(self, "broadcast_calls", 0))

@@ -195,3 +195,104 @@ def test_bf16_wire_and_flat_broadcast_gloo_world2():
         p.join(timeout=60)
     for rank, status, info in out:
         assert status == "ok", f"rank {rank}: {info}"
+
+
+def test_bench_workload_per_rank_is_the_same_at_every_world_size():
+    """the driver computes scaling efficiency from bench.py's N = 1, 2, 4, 8 lines, so the default
+    workload must give every rank the SAME per-GPU batch at every N (BASELINE.json configs[2]: 256 trees global = 32 per
+    GPU, 64 comments each).  --variable-trees is the opt-in balancing demonstration."""
+    import bench
+    kw = dict(trees_per_gpu=4, nodes=16, image_frac=0.25, image_size=32, patch=16, shape="bushy")
+    one = bench.trees_for_rank(3, 0, 1, **kw)
+    n1 = sum(len(t["parent"]) for t in one)
+    i1 = sum(int(t["image_index"].sum()) for t in one)
+    tok1 = sum(int(t["attention_mask"].sum()) for t in one)
+    assert n1 == 4 * 16 and i1 == 4 * 4
+    for world in (2, 4, 8):
+        shares = [bench.trees_for_rank(3, r, world, **kw) for r in range(world)]
+        assert [len(s) for s in shares] == [4] * world
+        assert [sum(len(t["parent"]) for t in s) for s in shares] == [n1] * world
+        assert [sum(int(t["image_index"].sum()) for t in s) for s in shares] == [i1] * world
+        # ragged text: valid-token counts differ per tree (U{8..100}) but the expectation per rank is the same
+        tok = [sum(int(t["attention_mask"].sum()) for t in s) for s in shares]
+        assert max(tok) / min(tok) < 1.35 and abs(sum(tok) / world / tok1 - 1.0) < 0.35
+        # disjoint cover of the global batch
+        ids = sorted(id(t["input_ids"]) for s in shares for t in s)
+        assert len(set(ids)) == 4 * world
+    var = [bench.trees_for_rank(3, r, 2, variable=True, **kw) for r in range(2)]
+    assert sum(len(t["parent"]) for s in var for t in s) < 2 * n1          # opt-in: smaller trees, NOT the N = 1 workload
+
+
+def _worker_verify(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        from multimodaldiscussiontransformer_amd.ddp import DataParallel, GradientBucketer
+        # a stand-in "model": DataParallel only needs prepare_main_grads / parameters / the encoder hook slot
+        torch.manual_seed(5)
+        params = [torch.nn.Parameter(torch.randn(s)) for s in ((50, 8), (8,), (64, 4), (300,), (7, 7))]
+
+        class M(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.ps = torch.nn.ParameterList(params)
+                self.encoder = SimpleNamespace(graph_encoder=SimpleNamespace(grad_ready_hook=None))
+
+            def prepare_main_grads(self):
+                self.main_grad_flat = torch.zeros(sum(p.numel() for p in params))
+                off = 0
+                for p in params:
+                    p.main_grad = self.main_grad_flat[off:off + p.numel()].view(p.shape)
+                    off += p.numel()
+                return self.main_grad_flat
+
+        model = M()
+        dp = DataParallel(model, bucket_mb=1)
+        dp.bucketer.bucket_elems = 200                      # several buckets
+        hook = model.encoder.graph_encoder.grad_ready_hook
+
+        def run_step():
+            dp.zero_grad()
+            g = torch.Generator().manual_seed(77 + rank)
+            for p in reversed(params):                      # "backward": last parameter first
+                p.main_grad.add_(torch.randn(p.shape, generator=g))
+                hook([p])
+            dp.finish_backward(torch.tensor([0.0, 2.0, 0, 0, 0, 0]))
+
+        run_step()                                          # first step: whole arena, then the completion-ordered layout
+        assert dp.bucketer.layout_final and len(dp.bucketer.bucket_ends) >= 3
+        res = dp.verify_exchange(run_step)
+        assert res["ok"] and res["replicas_equal"] and res["overlapped_launches"] == len(dp.bucketer.bucket_ends), res
+        assert res["overlapped_vs_deferred_rel_l2"] == 0.0 and res["bucketed_vs_flat_rel_l2"] < 1e-6, res
+        assert not dp.bucketer.defer
+        # a rank that issues its buckets in another order sums mismatched slices: the replicas disagree and the check says so
+        dp.zero_grad()
+        for p in params:
+            p.main_grad.fill_(1.0 + rank)
+        dp.bucketer.flat[:4].fill_(5.0 if rank == 0 else 1.0)          # emulate a mismatched reduction result on one rank
+        chk = dp.replicas_checksum()
+        assert not chk["replicas_equal"] and chk["checksum_max_abs_diff"] > 0
+        d = dp.diagnostics()
+        assert d["world_seen_by_backend"] == world and d["backend_seen"] == "gloo" and d["launches_last_step"] >= 1
+        q.put((rank, "ok", 0))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_self_check_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_verify, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info in out:
+        assert status == "ok", f"rank {rank}: {info}"

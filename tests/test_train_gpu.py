@@ -140,12 +140,14 @@ def test_rccl_bucketed_exchange_world1_equals_plain_backward(monkeypatch):
     crit = GraphPredictionNodeCrossEntropy(None, positive_weight=1.5, negative_weight=1.0)
     pb = pack_batch(trees, 5)
 
-    def run(force):
+    checks = {}
+
+    def run(force, wire=None):
         monkeypatch.setenv("MDT_DDP_FORCE", "1" if force else "0")
         model = GraphormerModel.build_model(model_args(hp), task=None)
         fill_hash_weights(model)
         model = model.cuda().eval()
-        dp = DataParallel(model, bucket_mb=8)
+        dp = DataParallel(model, bucket_mb=8, wire_dtype=wire)
         assert dp.bucketer.active == force
         out = None
         for step in range(3):
@@ -159,7 +161,23 @@ def test_rccl_bucketed_exchange_world1_equals_plain_backward(monkeypatch):
             if force and step > 0:
                 assert len(dp.bucketer.bucket_ends) > 2
         torch.cuda.synchronize()
-        return {n_: p.main_grad.detach().clone() for n_, p in model.named_parameters() if hasattr(p, "main_grad")}
+        res = {n_: p.main_grad.detach().clone() for n_, p in model.named_parameters() if hasattr(p, "main_grad")}
+        if force and wire is None:
+            # the self-check bench.py runs at N > 1 (replicas equal, overlapped == deferred == one flat all-reduce) and the
+            # diagnostics of the stream-ordered path: one event bracket per bucket that covers the collective itself
+            def same_step():
+                dp.zero_grad()
+                loss_, n__, _ = crit(model, {"nsamples": len(trees), "net_input": {"batched_data": pb.batched_data}})
+                loss_.backward()
+                sc = torch.zeros(6, device="cuda")
+                sc[1].fill_(float(n__))
+                dp.finish_backward(sc)
+                torch.cuda.synchronize()
+            d = dp.diagnostics()
+            assert d["stream_ordered_waits"] and d["backend_seen"] == "nccl" and len(d["bucket_allreduce_ms"]) == d["buckets"], d
+            assert d["overlap"] is not None and 0.0 <= d["overlap"]["overlap_frac"] <= 1.0, d
+            checks["verify"] = dp.verify_exchange(same_step)
+        return res
 
     plain = run(False)
     created = not dist.is_initialized()
@@ -171,12 +189,18 @@ def test_rccl_bucketed_exchange_world1_equals_plain_backward(monkeypatch):
             pytest.skip(f"cannot create a world-size-1 RCCL group here: {e}")
     try:
         forced = run(True)
+        wired = run(True, wire=torch.bfloat16)      # bf16 copies on the wire, reduced copy written back on the comm stream
     finally:
         if created:
             dist.destroy_process_group()
     assert set(plain) == set(forced)
     for n_ in plain:
         torch.testing.assert_close(forced[n_], plain[n_], atol=2e-5 * max(1.0, float(plain[n_].abs().max())), rtol=1e-4, msg=n_)
+        # bf16 wire: every element went through one bf16 rounding (relative 2^-9), nothing else — a copy-back that raced the
+        # collective (the copy ran on a stream that had not waited for it) leaves unreduced or torn values
+        torch.testing.assert_close(wired[n_], plain[n_], atol=1e-6 + 4e-3 * float(plain[n_].abs().max()), rtol=4e-3, msg="bf16 wire: " + n_)
+    v = checks["verify"]
+    assert v["ok"] and v["replicas_equal"] and v["overlapped_vs_deferred_rel_l2"] < 1e-4 and v["bucketed_vs_flat_rel_l2"] < 1e-4, v
 
 
 def test_launcher_does_not_train_the_shipped_recipe_from_random_encoders():

@@ -63,6 +63,13 @@ for k in fe:
                              bytes_per_launch=round((fb + wb) / n))
 g = [out["kernels"][k] for k in ("gemm_bf16_w4p", "gemm_bf16_pp256p", "gemm_bf16_pp256", "gemm_bf16_tile128") if k in out["kernels"]]
 tl = sum(x["launches"] for x in g)
+sys.path.insert(0, root)
+try:
+    import bench
+    out["code_state_hash"] = bench.code_state_hash()       # bench.py quotes these numbers only while the code is this
+except Exception as e:  # noqa: BLE001
+    out["code_state_hash"] = None
+    print("no code hash:", e)
 out["gemm_family_bytes_per_launch"] = round(sum(x["bytes_per_launch"] * x["launches"] for x in g) / tl)
 json.dump(out, open(dst + "_pmc_traffic.json", "w"), indent=1)
 print("saved", dst + "_*", "gemm family bytes/launch", out["gemm_family_bytes_per_launch"])
