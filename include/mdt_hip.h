@@ -64,6 +64,9 @@ enum {
 
 int mdt_abi_version(void);
 const char* mdt_last_error_string(void);
+/* sha256 (hex) over csrc/ and this header at the time the library was linked (build.py source_hash()): the Python side
+ * refuses a libmdt_hip.so that was not built from the sources next to it. */
+const char* mdt_source_hash(void);
 
 /* ------------------------------------------------------------------ GEMM
  * C[M,N] = epilogue( alpha * op(A)[M,K] @ op(B)[K,N] )

@@ -43,6 +43,7 @@ class AttnBwdArgs(C.Structure):
 _SIGS = {
     "mdt_abi_version": ([], _i),
     "mdt_last_error_string": ([], C.c_char_p),
+    "mdt_source_hash": ([], C.c_char_p),
     "mdt_gemm": ([_vp, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _f, _vp, _vp, _i64,
                   _vp, _i64, _i, _f, C.c_uint64, _vp], _i),
     "mdt_gemm_tile_queue_bytes": ([], C.c_size_t),
@@ -102,6 +103,13 @@ def _load():
         fn.restype = res
     if lib.mdt_abi_version() != 1:
         raise ImportError("libmdt_hip.so ABI version mismatch")
+    # the .so is git-ignored and travels to the GPU box prebuilt: it must be the build of the csrc/ next to it
+    if os.environ.get("MDT_SKIP_SOURCE_HASH") != "1" and os.path.isdir(os.path.join(_HERE, "csrc")):
+        from .build import source_hash
+        built, here = lib.mdt_source_hash().decode(), source_hash()
+        if built != here:
+            raise ImportError(f"{LIB_PATH} was built from other sources (library {built[:16]}, csrc/ {here[:16]}): rebuild with "
+                              "`python -m multimodaldiscussiontransformer_amd.build` (MDT_SKIP_SOURCE_HASH=1 overrides, for A/B runs of two builds)")
     return lib
 
 

@@ -16,6 +16,19 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-res
 EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "attention_v2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
+def source_hash() -> str:
+    """sha256 over every file of csrc/ and include/mdt_hip.h (names and contents, sorted): what the linked library is
+    stamped with (mdt_source_hash) and what _lib.py recomputes at import."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".hpp", ".h")))
+    files.append(os.path.join(HERE, "..", "include", "mdt_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -48,8 +61,17 @@ def build(verbose: bool = False, force: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(OUT, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    # the stamp: a generated translation unit holding the hash of the sources this link was made from
+    digest = source_hash()
+    stamp_src = os.path.join(objdir, "source_hash.cpp")
+    stamp_obj = os.path.join(objdir, "source_hash.o")
+    text = f'extern "C" const char* mdt_source_hash(void) {{ return "{digest}"; }}\n'
+    if not os.path.exists(stamp_src) or open(stamp_src).read() != text or not os.path.exists(stamp_obj):
+        open(stamp_src, "w").write(text)
+        run([os.environ.get("CXX", "g++"), "-O1", "-fPIC", "-c", stamp_src, "-o", stamp_obj])
+        jobs.append(None)
+    if force or jobs or _stale(OUT, objs + [stamp_obj]):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + [stamp_obj])
     return OUT
 
 

@@ -16,8 +16,10 @@ dict —
     task_state           {}
     extra_state          {"metrics", "previous_training_time", "train_iterator": {"epoch", ...}}
     last_optimizer_state torch-optimizer state dict of Adam: {"state": {i: {"step", "exp_avg", "exp_avg_sq"}},
-                         "param_groups": [{"lr", "betas", "eps", "weight_decay", "params": [i, ...]}]}  — one entry per
-                         parameter tensor in ``model.parameters()`` order (FairSeq's layout for fp32 training and for
+                         "param_groups": [{"lr", "betas", "eps", "weight_decay", "params": [0 .. T-1]}]}  — numbered over
+                         the TRAINABLE parameters in ``model.parameters()`` order, as torch numbers them (frozen ones are
+                         not counted; a parameter that never got a gradient has no ``state`` entry), FairSeq's layout for
+                         fp32 training and for
                          ``--fp16-no-flatten-grads``; its flattened-fp32-copy layout holds a single entry instead and is
                          accepted on load when the element counts add up)
 
@@ -58,51 +60,78 @@ def _model_state_fp32(model, optimizer) -> "OrderedDict[str, torch.Tensor]":
     return out
 
 
-def optimizer_state_dict(optimizer, model) -> dict:
-    params = [p for p in model.parameters()]
+def _trainable(model, criterion=None):
+    """The list FairSeq builds its optimizer over (fairseq/trainer.py ``_build_optimizer``): the parameters of model then
+    criterion that require gradients, in ``parameters()`` order.  A torch / FairSeq Adam ``state_dict`` numbers exactly
+    these 0 .. T-1 — frozen parameters (``--freeze_initial_encoders``: the BERT / ViT prefix, which comes FIRST in
+    ``model.parameters()``) are not counted — and holds a ``state`` entry only for parameters that ever received a
+    gradient (the reference's dead parameters never do)."""
+    ps = [p for p in model.parameters() if p.requires_grad]
+    if criterion is not None:
+        ps += [p for p in criterion.parameters() if p.requires_grad]
+    return ps
+
+
+def optimizer_state_dict(optimizer, model, criterion=None) -> dict:
+    params = _trainable(model, criterion)
     index = {id(p): i for i, p in enumerate(params)}
-    state, ids = {}, []
+    state = {}
     for p in optimizer.params:
         i = index[id(p)]
         st = optimizer.state[id(p)]
-        ids.append(i)
         state[i] = {"step": optimizer.step_count, "exp_avg": st["m"].detach().cpu(), "exp_avg_sq": st["v"].detach().cpu()}
     group = {"lr": optimizer.lr, "betas": tuple(optimizer.betas), "eps": optimizer.eps, "weight_decay": optimizer.weight_decay,
-             "amsgrad": False, "params": ids}
+             "amsgrad": False, "params": list(range(len(params)))}
     return {"state": state, "param_groups": [group]}
 
 
-def load_optimizer_state_dict(optimizer, model, osd: dict):
-    params = [p for p in model.parameters()]
+def load_optimizer_state_dict(optimizer, model, osd: dict, criterion=None):
+    """Positional, as ``torch.optim.Optimizer.load_state_dict`` maps them: the ids listed in ``param_groups[*]["params"]``
+    (in order) belong to the trainable parameters (in order).  A parameter without a ``state`` entry (never stepped in
+    the run that wrote the checkpoint) starts from zero moments; shapes must agree exactly — a shifted numbering must
+    fail loudly, not broadcast another parameter's moments in."""
+    params = _trainable(model, criterion)
     st_in = osd["state"]
-    if len(st_in) == 1 and len(optimizer.params) > 1:
+    ids = [i for g in osd["param_groups"] for i in g["params"]]
+    if len(st_in) == 1 and len(ids) <= 1 and len(optimizer.params) > 1:
         # FairSeq FP16Optimizer with flattened fp32 copies: one flat tensor over the trainable parameters in order
         (flat,) = st_in.values()
-        total = sum(p.numel() for p in optimizer.params)
+        total = sum(p.numel() for p in params)
         if flat["exp_avg"].numel() != total:
             raise ValueError(f"flattened optimizer state holds {flat['exp_avg'].numel()} elements, the model has {total} trainable")
         off = 0
-        for p in optimizer.params:
-            st = optimizer.state[id(p)]
+        for p in params:
             n = p.numel()
-            st["m"].copy_(flat["exp_avg"].view(-1)[off:off + n].view(p.shape))
-            st["v"].copy_(flat["exp_avg_sq"].view(-1)[off:off + n].view(p.shape))
+            st = optimizer.state.get(id(p))
+            if st is not None:
+                st["m"].copy_(flat["exp_avg"].view(-1)[off:off + n].view(p.shape))
+                st["v"].copy_(flat["exp_avg_sq"].view(-1)[off:off + n].view(p.shape))
             off += n
-        optimizer.step_count = int(flat.get("step", 0))
+        step = flat.get("step", 0)
+        optimizer.step_count = int(step.item() if torch.is_tensor(step) else step)
     else:
-        index = {id(p): i for i, p in enumerate(params)}
+        if len(ids) != len(params):
+            raise ValueError(f"optimizer state numbers {len(ids)} parameters, the model has {len(params)} trainable ones "
+                             f"(frozen parameters are not numbered: check --freeze_initial_encoders against the checkpoint)")
+        key_of = {id(p): k for p, k in zip(params, ids)}
         steps = set()
         for p in optimizer.params:
-            i = index[id(p)]
-            if i not in st_in:
-                raise KeyError(f"optimizer state has no entry for parameter #{i}")
             st = optimizer.state[id(p)]
-            st["m"].copy_(st_in[i]["exp_avg"])
-            st["v"].copy_(st_in[i]["exp_avg_sq"])
-            steps.add(int(st_in[i]["step"]))
-        if len(steps) != 1:
+            ent = st_in.get(key_of[id(p)])
+            if ent is None:                          # never stepped in the run that wrote the checkpoint: zero moments
+                st["m"].zero_()
+                st["v"].zero_()
+                continue
+            for name, dst in (("exp_avg", st["m"]), ("exp_avg_sq", st["v"])):
+                if tuple(ent[name].shape) != tuple(dst.shape):
+                    raise ValueError(f"optimizer state #{key_of[id(p)]}: {name} has shape {tuple(ent[name].shape)}, the parameter "
+                                     f"at that position has {tuple(dst.shape)}")
+                dst.copy_(ent[name])
+            step = ent["step"]
+            steps.add(int(step.item() if torch.is_tensor(step) else step))
+        if len(steps) > 1:
             raise ValueError(f"per-parameter step counts differ: {sorted(steps)}")
-        optimizer.step_count = steps.pop()
+        optimizer.step_count = steps.pop() if steps else 0
     g = osd["param_groups"][0]
     optimizer.lr, optimizer.betas, optimizer.eps, optimizer.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
 

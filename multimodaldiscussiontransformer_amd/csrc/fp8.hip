@@ -34,8 +34,13 @@ __global__ __launch_bounds__(256) void fp8_quantize_kernel(int64_t rows, int64_t
     int w0 = 0, w1 = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      amax = fmaxf(amax, fabsf(v[e]));
-      v[e] = fminf(fmaxf(v[e] * scale, -FMAX), FMAX);   // saturate: the formats have no room above FMAX (e4m3fn: NaN)
+      // fmaxf / fminf drop a NaN operand: a diverged activation must stay visible — it goes through as NaN (the fp8 NaN
+      // code, which the MFMA propagates into the product and on to the loss, as the bf16 path would) and it marks the
+      // running maximum as +inf, which fp8_scale_update leaves the scale alone for
+      const float x = v[e] * scale;
+      const bool bad = !(fabsf(v[e]) <= 3.0e38f);      // NaN or infinity
+      amax = bad ? __builtin_inff() : fmaxf(amax, fabsf(v[e]));
+      v[e] = (x != x) ? x : fminf(fmaxf(x, -FMAX), FMAX);   // saturate: the formats have no room above FMAX (e4m3fn: NaN)
     }
     if constexpr (FMT == 0) {
       w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w0, true);

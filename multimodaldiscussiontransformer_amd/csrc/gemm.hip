@@ -2096,8 +2096,9 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   p.group_n = 1 << 30;   // row-major unless launch_pp256 decides otherwise
   p.epilogue |= switches().gemm_diag << 20;   // diagnostics: 1 skip stores, 2 sc1 stores, 4 skewed starts within an XCD, 8 every tile loads tile (0,0)'s panels, 64 XCDs skewed against each other, 256 row-panel groups skewed inside an XCD (4-wave kernel)
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_COLSUM) || (colsum && split_k == 1), "mdt_gemm: MDT_EPI_COLSUM needs a colsum buffer and split_k == 1");
-  MDT_CHECK_ARG(!(epilogue & MDT_EPI_ASUM) || (colsum && trans_a && (epilogue & MDT_EPI_ATOMIC) && !(epilogue & MDT_EPI_COLSUM) && dtype == MDT_BF16),
-                "mdt_gemm: MDT_EPI_ASUM needs bf16 operands, trans_a = 1, MDT_EPI_ATOMIC, a colsum buffer and no MDT_EPI_COLSUM");
+  // (MDT_EPI_ATOMIC already implies an fp32 C; said again because the kernels compute the sums in their fp32-output form only)
+  MDT_CHECK_ARG(!(epilogue & MDT_EPI_ASUM) || (colsum && trans_a && (epilogue & MDT_EPI_ATOMIC) && !(epilogue & MDT_EPI_COLSUM) && dtype == MDT_BF16 && out_dtype == MDT_F32),
+                "mdt_gemm: MDT_EPI_ASUM needs bf16 operands, an fp32 C, trans_a = 1, MDT_EPI_ATOMIC, a colsum buffer and no MDT_EPI_COLSUM");
   // tile128 contract: bf16, output dims that are tiled along a contiguous axis must be
   // whole tiles, 16-B aligned rows.
   // MDT_EPI_ASUM rides on the 256 x 256 ping-pong kernel only; every other path sums the stored A ([K, M]) with the

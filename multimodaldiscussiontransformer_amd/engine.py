@@ -883,6 +883,8 @@ class TapeFunction(torch.autograd.Function):
         finally:
             tape._leave_side()
         tape.sync_streams()
+        if inference and F8.ACTIVE is not None:
+            F8.ACTIVE.end_of_step()      # no backward will close this pass: its |x| maxima become the next scales here (and are reset)
         ctx.tape, ctx.ins, ctx.outs = tape, ins, outs
         ctx.params = tensors[n_in:]
         ctx.n_in = n_in

@@ -90,8 +90,9 @@ class GraphFusionLayer(nn.Module):
         I, P = (vit_hidden_states.shape[0], vit_hidden_states.shape[1]) if have_img else (0, 0)
         Sv = nb + P
         if have_img:
-            img = torch.nonzero(x_image_indexes).flatten()
-            assert img.numel() == I
+            # positions of the image comments WITHOUT torch.nonzero (its output size is data-dependent: a D2H sync): I is known
+            # from the ViT tensor, and a stable sort of the negated mask lists the True positions first, in order
+            img = torch.sort((~x_image_indexes.bool()).to(torch.uint8), stable=True).indices[:I]
             j = torch.arange(nb, device=dev)
             img_text_rows = (img[:, None] * St + j[None]).to(torch.int32).reshape(-1).contiguous()
             vit_rows = (torch.arange(I, device=dev)[:, None] * Sv + j[None]).to(torch.int32).reshape(-1).contiguous()

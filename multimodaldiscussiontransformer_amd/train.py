@@ -1,8 +1,8 @@
 """Minimal ``fairseq-train``-compatible launcher for the HIP-backed mDT (fairseq itself is optional).
 
 Accepts the flags of mDT/experiments/hateful_discussions/run_train.sh:28-65 with the same
-spellings (unknown FairSeq flags such as --save-dir / --wandb-project are accepted and
-ignored with a note), resolves --task / --arch / --criterion / --dataset-name through
+spellings (flags it does not implement are refused; the few it accepts without effect —
+--wandb-project, --num-workers, --required-batch-size-multiple — say so on stderr), resolves --task / --arch / --criterion / --dataset-name through
 ``registry.py``, and runs the reference recipe: Adam(0.9, 0.999, eps 1e-8, wd 0.01),
 polynomial-decay LR with warm-up, --update-freq gradient accumulation, gradient scaling by
 1 / (global) sample size, bf16 (``--fp16`` in the reference) with fp32 master weights, RCCL
@@ -81,7 +81,11 @@ def build_parser():
     p.add_argument("--reset-dataloader", action="store_true", default=False)
     p.add_argument("--clip-norm", type=float, default=0.0)
     p.add_argument("--required-batch-size-multiple", type=int, default=1)
-    p.add_argument("--validate-interval-updates", type=int, default=0)
+    p.add_argument("--validate-interval-updates", type=int, default=0,
+                   help="run_train.sh:42 — every N updates (and after the last one) an eval-mode pass over --valid-subset")
+    p.add_argument("--valid-subset", default="valid")
+    p.add_argument("--disable-validation", action="store_true", default=False)
+    p.add_argument("--synthetic-valid-batches", type=int, default=2)
     p.add_argument("--wandb-project", default=None)
     # synthetic data controls
     p.add_argument("--synthetic-nodes", type=int, default=16)
@@ -130,6 +134,12 @@ def main(argv=None):
         raise SystemExit("[mdt-train] --clip-norm is not implemented (the reference launch does not use it)")
     if args.wandb_project:
         print("[mdt-train] --wandb-project: metrics are printed as JSON lines, nothing is sent to wandb", file=sys.stderr)
+    # accepted for launch-script compatibility, without effect here — said, not silent
+    if args.num_workers:
+        print("[mdt-train] --num-workers: ignored — batches are packed by the native packer in ONE prefetch thread (data/prefetch.py)", file=sys.stderr)
+    if args.required_batch_size_multiple != 1:
+        print("[mdt-train] --required-batch-size-multiple: ignored — batches hold exactly --batch-size trees (the last one of an epoch may be smaller)",
+              file=sys.stderr)
     import torch.distributed as dist
     from .ddp import DataParallel
     from .optim import FusedAdam, PolynomialDecayLR
@@ -183,6 +193,10 @@ def main(argv=None):
                                   missing=len(info["missing"]), unexpected=len(info["unexpected"]))), flush=True)
         dp.broadcast_parameters()
 
+    skip_batches = 0          # batches of the running epoch that the restored checkpoint had already consumed
+    if args.restore_file and not args.reset_dataloader:
+        skip_batches = int(((info["extra_state"].get("train_iterator") or {}).get("iterations_in_epoch", 0)) or 0)
+    valid_batches = None      # callable → iterable of packed batches of the held-out split (this rank's share)
     if args.dataset_name == "synthetic":
         batches = synthetic_batches(args, task, rank)
         n_batches = len(batches)
@@ -190,27 +204,40 @@ def main(argv=None):
         def batch_stream():
             while True:
                 yield from batches
+
+        if not args.disable_validation and args.synthetic_valid_batches > 0:
+            import copy
+            va = copy.copy(args)
+            va.seed, va.synthetic_batches = args.seed + 104729, args.synthetic_valid_batches     # trees the training stream never shows
+            held_out = synthetic_batches(va, task, rank)
+            valid_batches = lambda: held_out      # noqa: E731
     elif task.dm is None:
         raise SystemExit(f"[mdt-train] dataset {args.dataset_name!r} is not registered: pass --user-data-dir <package whose "
                          "modules call register_dataset> (mDT/src/tasks/task.py:123-137) or --dataset-name synthetic")
     else:
         # a registered dataset (mDT/src/tasks/task.py:168-204): rank r takes every world-th batch of the epoch order;
-        # batches are packed, uploaded and indexed one step ahead by the prefetch thread
+        # batches are packed, uploaded and indexed one step ahead by the prefetch thread.  FairSeq keeps the last,
+        # partial batch of an epoch (no drop-last): the number of batches per epoch is the CEILING, which is also what
+        # --max-epoch turns into a number of updates.
         from .data.prefetch import Prefetcher
         task.collate_device = "cuda"
         ds = task.load_dataset("train")
-        n_batches = max(1, len(ds) // (args.batch_size * world))
+        per_step = args.batch_size * world
+        n_batches = max(1, (len(ds) + per_step - 1) // per_step)
 
         def index_stream():
-            epoch = epoch0
+            epoch, first = epoch0, skip_batches % n_batches
             while True:
                 if hasattr(ds, "set_epoch"):
                     ds.set_epoch(epoch)
                 order = list(ds.ordered_indices())
-                for b in range(n_batches):
+                for b in range(first, n_batches):
                     lo = (b * world + rank) * args.batch_size
-                    yield [int(i) for i in order[lo:lo + args.batch_size]]
-                epoch += 1
+                    idx = [int(i) for i in order[lo:lo + args.batch_size]]
+                    # the tail batch of an epoch may leave the last ranks without trees; collectives must stay matched, so such
+                    # a rank takes the tail batch's first tree again (at most world - 1 trees per epoch are seen twice)
+                    yield idx if idx else [int(order[min(b * per_step, len(order) - 1)])]
+                epoch, first = epoch + 1, 0
 
         ge = model.encoder.graph_encoder
 
@@ -224,6 +251,20 @@ def main(argv=None):
                 ge._prune_indices(pb, ix)
 
         batch_stream = lambda: Prefetcher(index_stream(), make, depth=2, warm=warm)   # noqa: E731
+        if not args.disable_validation:
+            try:
+                vds = task.load_dataset(args.valid_subset)
+            except (KeyError, ValueError, AttributeError, FileNotFoundError):
+                vds = None
+            if vds is not None and len(vds) > 0:
+                def valid_batches():
+                    order = list(range(len(vds)))
+                    nb_ = (len(order) + per_step - 1) // per_step
+                    for b in range(nb_):
+                        lo = (b * world + rank) * args.batch_size
+                        idx = order[lo:lo + args.batch_size]
+                        if idx:                         # held-out trees are counted once: a rank without a share sits the batch out
+                            yield vds.collater([vds[i] for i in idx])["net_input"]["batched_data"]["_packed"]
     stream = iter(batch_stream())
     if args.dataset_name == "synthetic" and start_update and not args.reset_dataloader:
         for _ in range(start_update * args.update_freq):        # resume the batch order where the checkpoint left it
@@ -235,10 +276,54 @@ def main(argv=None):
     t0 = time.time()
     lr_for = sched.for_update        # FairSeq's timing: update k runs with the rate of num_updates = k - 1
 
+    best = {"value": None}
+
     def save(path, upd):
+        done = skip_batches + it                     # batches consumed since the restored epoch began
         ckpt.save_checkpoint(path, model, args, optimizer=opt, num_updates=upd, criterion_name=crit_cls.__name__,
-                             lr_scheduler_state={"best": None}, epoch=epoch0 + (it // max(1, n_batches)),
-                             training_time=time.time() - t0)
+                             lr_scheduler_state={"best": best["value"]}, epoch=epoch0 + done // max(1, n_batches),
+                             training_time=time.time() - t0,
+                             extra_state={"train_iterator": {"version": 2, "epoch": epoch0 + done // max(1, n_batches),
+                                                             "iterations_in_epoch": done % max(1, n_batches), "shuffle": True},
+                                          "val_loss": best["value"]})
+
+    valid_history = []
+    main.valid_history = valid_history
+
+    def validate(upd):
+        """FairSeq's ``validate``: eval mode, no gradients, the summed logging outputs of every held-out batch (all ranks) go
+        through the criterion's own ``reduce_metrics`` arithmetic (criterions/hatespeech_loss.py:133-173: accuracy,
+        precision, recall, F1 with its zero guards)."""
+        if valid_batches is None:
+            return None
+        was = model.training
+        model.eval()
+        tot = torch.zeros(6, dtype=torch.float32, device="cuda")
+        keys = None
+        with torch.no_grad():
+            for pb in valid_batches():
+                loss, sample_size, log = crit(model, {"nsamples": pb.B, "net_input": {"batched_data": pb.batched_data}})
+                keys = [k for k in log if k not in ("loss", "sample_size", "nsentences", "ntokens")]
+                tot[0] += loss.detach().float()
+                tot[1] += float(sample_size)
+                tot[2:6] += torch.stack([log[k] for k in keys]).float()
+        model.train(was)
+        if world > 1:
+            dist.all_reduce(tot)
+        if keys is None:
+            keys = ["ncorrect", "num_positive_correct", "total_positive", "num_pred_positive"]
+        s_ = tot.tolist()
+        summed = dict(loss=s_[0], sample_size=s_[1], **dict(zip(keys, s_[2:6])))
+        crit_cls.reduce_metrics([summed])            # logs through fairseq.metrics when fairseq is there
+        m = {("valid_" + k): v for k, v in crit_cls.compute_metrics([summed]).items()}
+        m.update(valid_counters=summed, num_updates=upd, subset=args.valid_subset)
+        if best["value"] is None or m["valid_loss"] < best["value"]:
+            best["value"] = m["valid_loss"]
+        m["valid_best_loss"] = best["value"]
+        valid_history.append(m)
+        if rank == 0:
+            print(json.dumps(m), flush=True)
+        return m
 
     for upd in range(start_update + 1, max_update + 1):
         dp.zero_grad()
@@ -263,13 +348,18 @@ def main(argv=None):
             history.append(m)
             if rank == 0:
                 print(json.dumps(m), flush=True)
+        if args.validate_interval_updates > 0 and upd % args.validate_interval_updates == 0 and upd != max_update:
+            validate(upd)
         if rank == 0 and args.save_dir and not args.no_save and args.save_interval_updates > 0 and upd % args.save_interval_updates == 0:
             for path in ckpt.checkpoint_paths(args.save_dir, epoch0, upd):
                 save(path, upd)
+    if max_update > start_update:
+        validate(max_update)                         # FairSeq validates at the end of training as well
     if rank == 0 and args.save_checkpoint:
         save(args.save_checkpoint, max_update)
     if rank == 0 and args.save_dir and not args.no_save:
         save(os.path.join(args.save_dir, "checkpoint_last.pt"), max_update)
+    main.last_run = dict(model=model, criterion=crit, valid_batches=valid_batches, optimizer=opt)     # for tests / notebooks
     if world > 1:
         dist.destroy_process_group()
     return history

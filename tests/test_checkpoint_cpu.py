@@ -211,3 +211,53 @@ def test_fairseq_learning_rate_timing():
     assert abs(s.for_update(10821) - 3e-7) < 1e-15
     s0 = PolynomialDecayLR(1e-3, 1e-5, 0, 100, 1.0)
     assert s0.for_update(1) == 1e-3 and abs(s0.for_update(51) - ((1e-3 - 1e-5) * 0.5 + 1e-5)) < 1e-12
+
+
+def test_torch_adam_state_of_a_frozen_encoder_model_loads_positionally(tmp_path):
+    """a FairSeq / torch Adam ``last_optimizer_state`` numbers only the TRAINABLE parameters (0..T-1,
+    ``model.parameters()`` order) and has no entry for parameters that never received a gradient.  With the reference
+    launch's --freeze_initial_encoders the frozen BERT / ViT prefix comes first in ``model.parameters()``, so numbering
+    over all parameters shifts every index.  Build exactly such a state dict with torch.optim.Adam and load it."""
+    from multimodaldiscussiontransformer_amd import checkpoint as ck
+    from multimodaldiscussiontransformer_amd.optim import FusedAdam
+    hp, model = _tiny(freeze_initial_encoders=True)
+    every = list(model.parameters())
+    train = [p for p in every if p.requires_grad]
+    first_frozen = next(i for i, p in enumerate(every) if not p.requires_grad)
+    assert 0 < len(train) < len(every) and any(p.requires_grad for p in every[first_frozen:])   # frozen tensors sit IN FRONT of trainable ones
+    adam = torch.optim.Adam(train, lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01)
+    dead = {id(train[3]), id(train[-1])}                                       # never receive a gradient: no state entry
+    g = torch.Generator().manual_seed(3)
+    for _ in range(2):
+        for p in train:
+            p.grad = None if id(p) in dead else torch.randn(p.shape, generator=g) * 1e-2
+        adam.step()
+    osd = adam.state_dict()
+    assert len(osd["state"]) == len(train) - 2 and osd["param_groups"][0]["params"] == list(range(len(train)))
+    opt = FusedAdam(train, lr=3e-5)
+    ck.load_optimizer_state_dict(opt, model, osd)
+    assert opt.step_count == 2 and opt.betas == (0.9, 0.98) and opt.eps == 1e-6 and opt.lr == 1e-4
+    for p in train:
+        st = opt.state[id(p)]
+        if id(p) in dead:
+            assert float(st["m"].abs().max()) == 0.0 and float(st["v"].abs().max()) == 0.0
+        else:
+            assert torch.equal(st["m"], adam.state[p]["exp_avg"]) and torch.equal(st["v"], adam.state[p]["exp_avg_sq"])
+    # what this repo writes has the same numbering: torch's own optimizer loads it back
+    out = ck.optimizer_state_dict(opt, model)
+    assert out["param_groups"][0]["params"] == list(range(len(train)))
+    adam2 = torch.optim.Adam(train, lr=1.0)
+    adam2.load_state_dict({"state": {k: dict(v, step=torch.tensor(float(v["step"]))) for k, v in out["state"].items()},
+                           "param_groups": [dict(adam2.state_dict()["param_groups"][0], **{k: v for k, v in out["param_groups"][0].items() if k != "params"})]})
+    for p in train:
+        if id(p) not in dead:
+            assert torch.equal(adam2.state[p]["exp_avg"], adam.state[p]["exp_avg"])
+    # a state dict numbered over ALL parameters (what round 2 wrote) has the wrong count and is refused, not broadcast in
+    bad = {"state": {i: {"step": 1, "exp_avg": torch.zeros(p.shape), "exp_avg_sq": torch.zeros(p.shape)} for i, p in enumerate(every)},
+           "param_groups": [dict(osd["param_groups"][0], params=list(range(len(every))))]}
+    with pytest.raises(ValueError, match="trainable"):
+        ck.load_optimizer_state_dict(opt, model, bad)
+    shifted = {"state": {0: {"step": 1, "exp_avg": torch.zeros(3, 5), "exp_avg_sq": torch.zeros(3, 5)}},
+               "param_groups": [dict(osd["param_groups"][0])]}
+    with pytest.raises(ValueError, match="shape"):
+        ck.load_optimizer_state_dict(opt, model, shifted)

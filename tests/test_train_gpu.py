@@ -2,6 +2,7 @@
 (Adam + polynomial decay, update-freq accumulation, bf16 with fp32 master weights, dropout on) on a small
 synthetic task whose label depends on the labelled comment's text — the loss must go down — plus the fused
 Adam kernel against torch's AdamW-equivalent formula."""
+import json
 import math
 
 import pytest
@@ -84,6 +85,47 @@ def test_launcher_trains_and_loss_decreases(tmp_path):
     sd = torch.load(ck)["model"]
     assert "encoder.graph_encoder.layers.0.layers.0.self_attn.q_proj.weight" in sd
     assert "encoder.graph_encoder.fusion_layers.0.fusion_layers.0.bert_encoder.attention.self.query.weight" in sd
+
+
+def test_launcher_validation_reports_the_criterions_f1(capsys):
+    """run_train.sh:42 (--validate-interval-updates): the launcher's held-out pass — eval mode, summed logging outputs →
+    the criterion's reduce_metrics arithmetic (hatespeech_loss.py:133-173) — prints accuracy / precision / recall / F1.
+    The F1 it prints must be compute_metrics over the per-batch logging outputs of the same batches, and the counters of a
+    mixed-prediction split must make F1 a real number in (0, 1]."""
+    from multimodaldiscussiontransformer_amd import train
+    argv = ["--task", "node_prediction", "--arch", "multi_graphormer_base", "--criterion", "node_cross_entropy",
+            "--dataset-name", "synthetic", "--batch-size", "16", "--max-update", "24", "--validate-interval-updates", "8",
+            "--lr", "5e-4", "--end-learning-rate", "1e-5", "--warmup-updates", "3", "--total-num-update", "24",
+            "--encoder-embed-dim", "128", "--encoder-ffn-embed-dim", "128", "--encoder-attention-heads", "2",
+            "--num_fusion_layers", "0", "--num_bottleneck_tokens", "2", "--attention-dropout", "0.1", "--act-dropout", "0.1",
+            "--dropout", "0.1", "--spatial-pos-max", "5", "--positive-weight", "1.5", "--negative-weight", "1", "--log-interval", "8",
+            "--synthetic-nodes", "6", "--synthetic-seq-len", "12", "--synthetic-batches", "4", "--synthetic-valid-batches", "3",
+            "--seed", "5", "--no-save", "--num-workers", "4",
+            "--bert-config", '{"dim": 128, "layers": 2, "heads": 2, "intermediate": 128, "vocab": 512, "max_pos": 64}',
+            "--vit-config", '{"dim": 128, "layers": 2, "heads": 2, "intermediate": 128, "image_size": 32, "patch": 16}']
+    train.main(argv)
+    vh = train.main.valid_history
+    assert [v["num_updates"] for v in vh] == [8, 16, 24]
+    printed = [json.loads(line) for line in capsys.readouterr().out.splitlines() if line.startswith("{") and "valid_f1" in line]
+    assert len(printed) == 3 and printed[-1]["valid_f1"] == vh[-1]["valid_f1"]
+    run = train.main.last_run
+    model, crit = run["model"], run["criterion"]
+    assert model.training                                   # the pass put the model back into training mode
+    model.eval()
+    logs = []
+    with torch.no_grad():
+        for pb in run["valid_batches"]():
+            _, _, log = crit(model, {"nsamples": pb.B, "net_input": {"batched_data": pb.batched_data}})
+            logs.append({k: float(v) for k, v in log.items()})
+    model.train()
+    want = type(crit).compute_metrics(logs)
+    last = vh[-1]
+    for k in ("loss", "accuracy", "precision", "recall", "f1"):
+        assert abs(last["valid_" + k] - want[k]) <= 1e-6 * max(1.0, abs(want[k])), (k, last["valid_" + k], want[k])
+    c = last["valid_counters"]
+    assert c["sample_size"] == 3 * 16 and 0 < c["total_positive"] < c["sample_size"]
+    assert 0.0 <= last["valid_f1"] <= 1.0 and last["valid_best_loss"] == min(v["valid_loss"] for v in vh)
+    assert vh[-1]["valid_loss"] < vh[0]["valid_loss"]       # the text-only rule is learnable: held-out loss falls too
 
 
 def test_restore_file_resumes_training(tmp_path):

@@ -1,6 +1,7 @@
 # In-call A/B of two builds of libmdt_hip.so (gpurun_lib_old.so / gpurun_lib_new.so in the repo root): boxes differ by
 # several per cent, so both arms must run inside ONE gpurun call.  Usage: gpurun -- 'bash tools/ab_libs.sh [cmd...]'
 set -e
+export MDT_SKIP_SOURCE_HASH=1   # two builds against one csrc/: the import-time source-hash check is for shipped trees
 L=multimodaldiscussiontransformer_amd/libmdt_hip.so
 out=gpurun_out/ab_libs.log; rm -f $out
 cmd=${@:-python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-selfcheck}
