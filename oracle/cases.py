@@ -74,6 +74,14 @@ def real_hparams(kind):
         return R.hparams(dim=1024, enc_heads=16, graph_heads=16, enc_ffn=4096, graph_ffn=1024, text_layers=4,
                          vit_layers=4, num_fusion_layers=1, num_fusion_stack=1, num_graph_stack=1, num_bottleneck=4,
                          vocab_size=30522, max_pos=512, image_size=224, patch=14, pos_weight=1.5, neg_weight=1.0)
+    if kind == "C4F":    # configs[3] at its FULL depth: BERT-large / ViT-L/14 split 12 + 12, 12 executed graph layers
+        return R.hparams(dim=1024, enc_heads=16, graph_heads=16, enc_ffn=4096, graph_ffn=1024, text_layers=24,
+                         vit_layers=24, num_fusion_layers=11, num_fusion_stack=1, num_graph_stack=1, num_bottleneck=4,
+                         vocab_size=30522, max_pos=512, image_size=224, patch=14, pos_weight=1.5, neg_weight=1.0)
+    if kind == "C1":     # configs[0] exactly: Tiny mDT — 128-d, BERT-mini 2 + 2 (2 heads, FFN 512), 2 executed graph layers
+        return R.hparams(dim=128, enc_heads=2, graph_heads=8, enc_ffn=512, graph_ffn=128, text_layers=4,
+                         vit_layers=4, num_fusion_layers=1, num_fusion_stack=1, num_graph_stack=1, num_bottleneck=4,
+                         vocab_size=30522, max_pos=512, image_size=32, patch=16, pos_weight=1.5, neg_weight=1.0)
     if kind == "M":
         return tiny_hparams("A")
     raise KeyError(kind)
@@ -100,6 +108,16 @@ def real_trees(kind, hp):
         trees = [synthetic.make_tree(128, rng, seq_len=100, vocab_size=hp.vocab_size, image_frac=0.125,
                                      image_size=hp.image_size, shape="deep", min_len=8)]
         return _label_many(trees, every=2)
+    if kind == "C4F":    # one 128-comment deep thread; comments of at most 48 tokens and 8 image comments keep the fp32 CPU oracle's
+        rng = np.random.Generator(np.random.PCG64(4097))     # autograd graph (24 + 24 blocks at D 1024) near 10 GB
+        trees = [synthetic.make_tree(128, rng, seq_len=48, vocab_size=hp.vocab_size, image_frac=0.0625,
+                                     image_size=hp.image_size, shape="deep", min_len=8)]
+        return _label_many(trees, every=2)
+    if kind == "C1":     # configs[0]'s workload: 8 bushy 16-comment trees, text only, L = 100
+        rng = np.random.Generator(np.random.PCG64(128))
+        trees = [synthetic.make_tree(16, rng, seq_len=100, vocab_size=hp.vocab_size, image_frac=0.0,
+                                     image_size=hp.image_size, shape="bushy", min_len=8) for _ in range(8)]
+        return _label_many(trees, every=2)
     if kind == "M":
         rng = np.random.Generator(np.random.PCG64(515))
         spec = ((8, 0.25, "bushy"), (7, 0.0, "deep"), (5, 0.4, "bushy"), (4, 0.0, "deep"))
@@ -112,7 +130,7 @@ def real_trees(kind, hp):
 # node_classifier.bias per case: minus / plus half the median logit margin of the hash-weight model (measured once with
 # the oracle, tools/margin_probe.py), so that about half of the comments are predicted positive.  Applied identically
 # to the reference (gen_golden), the oracle (make_weights) and the product (tests.util_model.fill_hash_weights).
-_BIAS_SHIFT = {"C2": 0.68, "C4": 0.0874, "M": 1.0912}
+_BIAS_SHIFT = {"C2": 0.68, "C4": 0.0874, "M": 1.0912, "C1": -0.217}
 
 
 def weight_overrides(kind):

@@ -164,7 +164,7 @@ def full_case(kind):
         hp = cases.tiny_hparams(kind)
         return f"full_tiny768_{kind}.npz", hp, cases.tiny_trees(kind, hp), {}
     hp = cases.real_hparams(kind)
-    fname = {"M": "full_tiny768_M.npz", "C2": "full_c2_real.npz", "C4": None}[kind]
+    fname = {"M": "full_tiny768_M.npz", "C2": "full_c2_real.npz"}.get(kind)        # C4, C4F, C1: the reference cannot run D != 768
     return fname, hp, cases.real_trees(kind, hp), cases.weight_overrides(kind)
 
 

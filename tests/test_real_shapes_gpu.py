@@ -8,6 +8,13 @@
   "C4"  configs[3] mDT-large shapes: D 1024, 16 heads, FFN 4096, ViT-L/14 (P = 257, S = 261), one 128-comment
         deep-thread tree (T = 129, banded -inf mask).  Layers cut to 2 + 2 so the CPU oracle takes seconds; the
         reference cannot run D != 768, so the oracle (pinned at D = 768 by the goldens) is the checker.
+  "C1"  configs[0] EXACTLY, as a full model on the HIP path: Tiny mDT — D 128, BERT-mini split 2 + 2 (2 heads of 64, FFN
+        512), 2 executed graph layers (8 heads of 16), text only, 8 bushy 16-comment trees, L = 100.  The reference
+        hard-codes 768, so the D-parametric oracle — pinned at D = 768 by the goldens and at
+        D = 128 per module by graph_modules_d128.npz — is the checker.
+  "C4F" configs[3] at its FULL 12 + 12 depth (24 BERT-large / ViT-L/14 blocks each way, 12 executed graph layers), bf16,
+        one 128-comment deep thread: what depth compounding at D = 1024 does to the bf16 path, measured once against the
+        fp32 oracle on the same bf16-rounded weights (a ~2-minute CPU pass).
   "M"   tiny shapes, mixed predictions (TP / FP / FN / TN all non-zero).
 
 fp32: north_star's 1e-3 gate on logits and on EVERY parameter gradient, both text layouts; counters / F1 exact.
@@ -77,7 +84,7 @@ def product_run(kind, dtype, ragged, main_grad=False):
 
 
 @pytest.mark.parametrize("ragged", [False, True], ids=["padded", "ragged"])
-@pytest.mark.parametrize("kind", ["M", "C2", "C4"])
+@pytest.mark.parametrize("kind", ["M", "C1", "C2", "C4"])
 def test_fp32_real_shapes_vs_reference_golden_and_oracle(golden_dir, kind, ragged):
     from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
     o = oracle_run(kind, rounded=False)
@@ -176,6 +183,43 @@ def test_bf16_real_shapes_vs_fp32_oracle(kind):
     print(f"[{kind} bf16] logits |err| {d_logit:.3e}; {len(rows)} gradients; worst rel-L2: "
           + "; ".join(f"{n} {r:.3e} (|g| {rn:.2e}, {ne} el)" for r, n, rn, ne in rows[:6]))
     bad = [(n, r) for r, n, _, _ in rows if r > BF16_GRAD_REL_L2]
+    assert not bad, bad[:10]
+
+
+def test_bf16_large_config_at_full_depth_vs_fp32_oracle():
+    """configs[3]'s 12 + 12 blocks and 12 graph layers in bf16 against the fp32 oracle (same
+    bf16-rounded weights).  Gates are the C2 / C4 ones for the logits; for gradients the per-tensor relative L2 may grow
+    with depth — the bound below is what a first-layer tensor is allowed after 24 blocks, the printed table is the
+    measurement."""
+    o = oracle_run("C4F", rounded=True)
+    model, pb, loss, sample_size, log, logits, glob = product_run("C4F", torch.bfloat16, True, main_grad=True)
+    lg = logits.float().cpu()
+    d_logit = float((lg - o["logits"]).abs().max())
+    span = float(o["logits"].max() - o["logits"].min())
+    grads = {n: getattr(p, "main_grad", None) for n, p in named_canonical_params(model).items()}
+    rows = []
+    for name, ref in o["grads"].items():
+        if ref is None:
+            continue
+        gr = split_qkv_grad(name, grads)
+        assert gr is not None, name
+        rn = float(ref.double().norm())
+        if rn < 1e-6:
+            continue
+        floor = 0.5 if name == "node_classifier.bias" else 0.0
+        rows.append((float((gr.float().cpu().double() - ref.double()).norm()) / max(rn, floor), name, rn, ref.numel()))
+    rows.sort(reverse=True)
+    big = [r for r in rows if r[3] >= 1 << 16]
+    med = sorted(r[0] for r in rows)[len(rows) // 2]
+    print(f"[C4F bf16, 12 + 12 blocks, 12 graph layers] logits |err| {d_logit:.3e} (logit span {span:.3f}); {len(rows)} gradients, "
+          f"median rel-L2 {med:.3e}; worst: " + "; ".join(f"{n} {r:.3e} ({ne} el)" for r, n, rn, ne in rows[:6]))
+    assert d_logit < BF16_LOGIT_ABS, d_logit
+    assert abs(loss - o["loss"]) < 0.15 + 0.01 * abs(o["loss"])
+    margin = (o["logits"][:, 1] - o["logits"][:, 0])
+    clear = margin.abs() > 2 * BF16_LOGIT_ABS
+    assert bool(((margin > 0)[clear] == ((lg[:, 1] - lg[:, 0]) > 0)[clear]).all())
+    assert med < 3e-2, med
+    bad = [(n, r) for r, n, _, _ in big if r > 2 * BF16_GRAD_REL_L2]
     assert not bad, bad[:10]
 
 
