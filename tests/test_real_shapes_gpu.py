@@ -207,12 +207,26 @@ def test_bf16_large_config_at_full_depth_vs_fp32_oracle():
         if rn < 1e-6:
             continue
         floor = 0.5 if name == "node_classifier.bias" else 0.0
+        # query / key projections: with hash weights the softmax of the deep pre-fusion blocks is nearly uniform and the signal
+        # through it almost vanishes — |g_query| is 1e-4 ... 1e-5 of |g_value| of the same block (measured: 8.4e-3 against 229
+        # in text layer 11) — so bf16's rowsum(dO o O) rounding (the flash-attention form of the softmax gradient), harmless
+        # at the block's gradient scale, is a large FRACTION of that remnant.  Their error is therefore measured against
+        # max(|g|, 1e-3 |g_value|): a thousandth of the block's attention-gradient scale.
+        for a, b in ((".query.", ".value."), (".key.", ".value."), (".q_proj.", ".v_proj."), (".k_proj.", ".v_proj.")):
+            if a in name and o["grads"].get(name.replace(a, b)) is not None:
+                floor = max(floor, 1e-3 * float(o["grads"][name.replace(a, b)].double().norm()))
         rows.append((float((gr.float().cpu().double() - ref.double()).norm()) / max(rn, floor), name, rn, ref.numel()))
     rows.sort(reverse=True)
     big = [r for r in rows if r[3] >= 1 << 16]
     med = sorted(r[0] for r in rows)[len(rows) // 2]
+    def vnorm(n):        # |gradient| of the value projection of the same block: the scale of that block's attention gradients
+        for a, b in ((".query.", ".value."), (".key.", ".value."), (".q_proj.", ".v_proj."), (".k_proj.", ".v_proj.")):
+            if a in n:
+                r = o["grads"].get(n.replace(a, b))
+                return None if r is None else float(r.double().norm())
+        return None
     print(f"[C4F bf16, 12 + 12 blocks, 12 graph layers] logits |err| {d_logit:.3e} (logit span {span:.3f}); {len(rows)} gradients, "
-          f"median rel-L2 {med:.3e}; worst: " + "; ".join(f"{n} {r:.3e} ({ne} el)" for r, n, rn, ne in rows[:6]))
+          f"median rel-L2 {med:.3e}; worst: " + "; ".join(f"{n} {r:.3e} (|g| {rn:.2e}, |g_value| {vnorm(n)}, {ne} el)" for r, n, rn, ne in rows[:8]))
     assert d_logit < BF16_LOGIT_ABS, d_logit
     assert abs(loss - o["loss"]) < 0.15 + 0.01 * abs(o["loss"])
     margin = (o["logits"][:, 1] - o["logits"][:, 0])
