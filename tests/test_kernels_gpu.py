@@ -122,6 +122,38 @@ def test_gemm_wgrad_with_bias_gradient_riding(ops, rows, N, K, split):
     torch.testing.assert_close(gb.cpu(), ref_b, atol=2e-3 * (rows ** 0.5), rtol=1e-4)
 
 
+@pytest.mark.parametrize("rows,N,K,split,asum", [(30000, 768, 3072, 7, True), (30011, 3072, 768, 7, True), (20037, 2304, 768, 12, True),
+                                                 (30000, 768, 3072, 7, False), (1100, 1024, 1024, 4, False)])
+def test_gemm_wgrad_four_wave_split_k(ops, rows, N, K, split, asum, monkeypatch):
+    """gemm_bf16_w4s (gemm_wgrad.hip): the split-K weight gradient dW[N, K] = dY[rows, N]^T X[rows, K] in the 4-wave form —
+    both operands k-major, fp32 atomics into what the buffer held, the bias gradient riding in tile column 0
+    (MDT_EPI_ASUM), a reduction length that is not a multiple of 64 (zero-filled through the descriptor) and slabs as short
+    as four K-tiles — against fp32 torch and against the 8-wave kernel (MDT_GEMM_W4=0) on the same inputs."""
+    from multimodaldiscussiontransformer_amd import _lib as L
+    dy, x = rnd(rows, N, seed=41, scale=0.25).bfloat16(), rnd(rows, K, seed=42, scale=0.25).bfloat16()
+    w0, b0 = rnd(N, K, seed=43), rnd(N, seed=44)
+    dyd, xd = dev(dy), dev(x)
+    ref_w = (dev(w0).double() + dyd.double().t() @ xd.double()).float().cpu()
+    ref_b = b0 + dy.float().sum(0)
+    outs = {}
+    for w4 in ("2", "0"):
+        monkeypatch.setenv("MDT_GEMM_W4", w4)
+        L.reload_env()
+        gw, gb = dev(w0.clone()), dev(b0.clone())
+        ops.gemm(dyd, xd, trans_a=True, trans_b=True, out=gw, epilogue=ops.EPI_ATOMIC, split_k=split, asum=gb if asum else None)
+        torch.cuda.synchronize()
+        outs[w4] = (gw.cpu(), gb.cpu())
+        torch.testing.assert_close(outs[w4][0], ref_w, atol=2e-2, rtol=1e-4, msg=f"dW, MDT_GEMM_W4={w4}")
+        if asum:
+            torch.testing.assert_close(outs[w4][1], ref_b, atol=2e-3 * (rows ** 0.5), rtol=1e-4, msg=f"db, MDT_GEMM_W4={w4}")
+        else:
+            assert torch.equal(outs[w4][1], b0)
+    monkeypatch.delenv("MDT_GEMM_W4")
+    L.reload_env()
+    # the two kernels add the same per-slab partial sums (same k order inside a slab); only the atomics' order differs
+    torch.testing.assert_close(outs["2"][0], outs["0"][0], atol=2e-3, rtol=1e-5)
+
+
 @pytest.mark.parametrize("tb,kind", [(False, "bias"), (False, "dense"), (True, "plain"), (True, "res"), (False, "res"), (False, "plain"),
                                      (True, "mulaux"), (False, "mulaux"), (False, "gelu")])
 def test_gemm_four_wave_form_is_bit_identical(ops, tb, kind, monkeypatch):

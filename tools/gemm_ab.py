@@ -66,6 +66,14 @@ def combos(M):
         out = [("NN bias N1024", x768, r(1024, 768), dict(bias=r(1024))),
                ("NN bias+res+drop N1024", x768, r(1024, 768), dict(bias=r(1024), residual=r(M, 1024), drop_p=0.4, drop_seed=3)),
                ("NN plain N1024 K3072", x3072, r(1024, 3072), dict())]
+    if "--wgrad" in sys.argv:    # the split-K weight gradients of a block (dW = dY^T X, fp32 atomics, bias gradient riding): MDT_GEMM_W4=0 | 2
+        out = []
+        for (nm, dy_, x_) in [("wgrad qkv", x2304, x768), ("wgrad o", x768, x768), ("wgrad fc1", x3072, x768), ("wgrad fc2", x768, x3072)]:
+            n_out, k_in = dy_.shape[1], x_.shape[1]
+            tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
+            split = max(1, min(1024 // tiles, M // 1024))
+            out.append((f"{nm} split{split}", dy_, x_, dict(trans_a=True, trans_b=True, epilogue=ops.EPI_ATOMIC, split_k=split,
+                                                           asum=torch.zeros(n_out, device=dev), out=torch.zeros(n_out, k_in, device=dev))))
     if "--nn-dgrad" in sys.argv:   # the input-gradient launches against a pre-transposed weight copy (k-contiguous B) beside the k-major form
         out = []
         for (nm, xin, n_out, k_in, extra) in [("dqkv plain", x2304, 768, 2304, {}), ("do plain", x768, 768, 768, {}),
@@ -94,6 +102,26 @@ def main():
                 continue
             N = b.shape[1] if kw.get("trans_b") else b.shape[0]
             K = a.shape[1]
+            if kw.get("trans_a"):                 # weight gradient: [rows, N_out]^T [rows, K_in] — flops 2 rows N_out K_in
+                wg_rows, wg_n = a.shape
+                res = []
+                setenv(**{k: VARIANTS[0].get(k) for k in NAMES})
+                timeit(lambda: ops.gemm(a, b, **dict(kw)), iters=10)
+                for var in VARIANTS:
+                    setenv(**{k: var.get(k) for k in NAMES})
+                    kw["out"].zero_(); kw["asum"].zero_()
+                    ops.gemm(a, b, **dict(kw))
+                    torch.cuda.synchronize()
+                    keep = [kw["out"].clone(), kw["asum"].clone()]
+                    t = timeit(lambda: ops.gemm(a, b, **dict(kw)))
+                    res.append((t, keep))
+                same = all(all(torch.allclose(x, y, rtol=1e-3, atol=2e-2) for x, y in zip(res[0][1], r[1])) for r in res[1:])
+                fl = 2.0 * wg_rows * wg_n * N
+                for i, r in enumerate(res):
+                    tot[i] += r[0]
+                cells = " | ".join(f"{r[0]*1e6:7.1f} us {fl/r[0]/1e12:5.0f} TF/s x{res[0][0]/r[0]:.3f}" for r in res)
+                print(f"{name:34s} dW {wg_n:5d}x{N:5d} rows={wg_rows}  {cells}  {'same' if same else 'DIFFERENT'}", flush=True)
+                continue
             res = []
             setenv(**{k: VARIANTS[0].get(k) for k in NAMES})      # throw-away pass: the first timed variant of a row otherwise
             timeit(lambda: ops.gemm(a, b, **dict(kw)), iters=10)  # pays the clock ramp / cold caches (3-10 % on these launches)
