@@ -334,6 +334,26 @@ int mdt_pack_structure(int B, const int64_t* n_nodes, const int64_t* const* pare
 int mdt_pack_structure_ud(int B, const int64_t* n_nodes, const int64_t* const* parents, const int64_t* const* updown,
                           int nmax, int spatial_pos_max, float* attn_bias, int32_t* spatial_pos, int64_t* in_degree);
 
+/* ------------------------------------------------------------------ image front end
+ * Replaces the ViTImageProcessor call of the reference's dataset builder
+ * (mDT/experiments/hateful_discussions/datasets/hateful_discussions.py:47-49,168-184): PIL bilinear (antialiased) resize to
+ * out_size x out_size, x * rescale (double, rounded once to float), (x - mean) / std (float) — for a batch of decoded RGB images
+ * of different sizes, on the device, byte-exact against PIL's resampler.
+ *   mdt_resize_plan_ksize / mdt_resize_plan (HOST): the taps of one axis — bounds[2 * out_size] = (first source sample,
+ *     tap count) per output sample, coeffs[out_size * ksize] 22-bit fixed-point weights (Pillow Resample.c precompute_coeffs +
+ *     normalize_coeffs_8bpc restated).
+ *   mdt_image_norm_lut (HOST): lut[3 * 256] = ((float)(u * rescale) - mean[c]) / std[c].
+ *   mdt_image_preprocess (DEVICE pointers): pixels = the images' HWC uint8 bytes back to back; desc[n][8] (int64) =
+ *     {pixel byte offset, tmp byte offset, H, W, horizontal plan offset, horizontal ksize, vertical plan offset, vertical ksize};
+ *     plan (int32) = at each plan offset the bounds followed by the coeffs of that axis; tmp = scratch of sum_i H_i * out_size * 3
+ *     bytes; out = [n, 3, out_size, out_size] in out_dtype (may be NULL), out_u8 = [n, out_size, out_size, 3] resized bytes (may
+ *     be NULL); max_h = the largest H. */
+int mdt_resize_plan_ksize(int in_size, int out_size);
+int mdt_resize_plan(int in_size, int out_size, int32_t* bounds, int32_t* coeffs, int ksize);
+int mdt_image_norm_lut(double rescale, const float* mean3, const float* std3, float* lut);
+int mdt_image_preprocess(void* stream, int n_images, int max_h, const uint8_t* pixels, const int64_t* desc, const int32_t* plan,
+                         uint8_t* tmp, const float* lut, int out_dtype, void* out, uint8_t* out_u8, int out_size);
+
 #ifdef __cplusplus
 }
 #endif

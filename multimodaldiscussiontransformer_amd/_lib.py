@@ -80,6 +80,10 @@ _SIGS = {
     "mdt_cast": ([_vp, _i, _i, _i64, _vp, _vp], _i),
     "mdt_transpose2d": ([_vp, _i, _i, _i64, _i64, _vp, _i64, _vp, _i64], _i),
     "mdt_adam_step": ([_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _vp], _i),
+    "mdt_resize_plan_ksize": ([_i, _i], _i),
+    "mdt_resize_plan": ([_i, _i, _vp, _vp, _i], _i),
+    "mdt_image_norm_lut": ([C.c_double, _vp, _vp, _vp], _i),
+    "mdt_image_preprocess": ([_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i], _i),
     "mdt_pack_structure": ([_i, _vp, _vp, _i, _i, _vp, _vp, _vp], _i),
     "mdt_pack_structure_ud": ([_i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp], _i),
 }

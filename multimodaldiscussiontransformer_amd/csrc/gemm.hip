@@ -1613,7 +1613,7 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   // fp32-accumulating launches (the split-K weight gradients) with at least four 64-deep K-tiles per slab: the 4-wave kernel
   // of gemm_wgrad.hip (MDT_GEMM_W4=0 keeps the 8-wave ping-pong kernel below)
   if (!persist && sizeof(TOut) == 4 && sw.gemm_w4 != 0 && !sw.gemm_stamp && (p.epilogue & MDT_EPI_ATOMIC) &&
-      !(p.epilogue & ~(MDT_EPI_ATOMIC | MDT_EPI_ASUM)) && p.k_chunk >= 256 && (p.K - (int64_t)(p.split_k - 1) * p.k_chunk) >= 256)
+      !(p.epilogue & ((1 << 20) - 1) & ~(MDT_EPI_ATOMIC | MDT_EPI_ASUM)) && p.k_chunk >= 256 && (p.K - (int64_t)(p.split_k - 1) * p.k_chunk) >= 256)
     return launch_w4s(st, p, ta, tb);
   const bool stamp = sw.gemm_stamp;
   const size_t nwg = (size_t)grid.x * grid.z;

@@ -60,13 +60,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int nhs = 2 * (int)((kend - kbeg + 63) / 64);          // 32-deep steps (even; the host guarantees >= 8)
 
   const int64_t lda_b = p.lda * 2, ldb_b = p.ldb * 2;
+  // diagnostic (MDT_GEMM_DIAG=8): every work item LOADS the panels of item (slab 0, tile (0, 0)) — all fills hit L2 — while
+  // the atomics still go to the item's own place: separates the fill's miss path from the loop's own cost
+  const bool diag_l2 = (p.epilogue & (1 << 23)) != 0;
+  const int64_t lm0 = diag_l2 ? 0 : m0, ln0 = diag_l2 ? 0 : n0, lk0 = diag_l2 ? 0 : kbeg;
   const char* a_base;
   const char* b_base;
   int64_t a_bytes, b_bytes;
-  if constexpr (!A_KM) { a_base = (const char*)p.A + m0 * lda_b + kbeg * 2; a_bytes = (p.M - m0) * lda_b - kbeg * 2; }
-  else { a_base = (const char*)p.A + kbeg * lda_b + m0 * 2; a_bytes = (kend - kbeg) * lda_b - m0 * 2; }
-  if constexpr (!B_KM) { b_base = (const char*)p.B + n0 * ldb_b + kbeg * 2; b_bytes = (p.N - n0) * ldb_b - kbeg * 2; }
-  else { b_base = (const char*)p.B + kbeg * ldb_b + n0 * 2; b_bytes = (kend - kbeg) * ldb_b - n0 * 2; }
+  if constexpr (!A_KM) { a_base = (const char*)p.A + lm0 * lda_b + lk0 * 2; a_bytes = (p.M - lm0) * lda_b - lk0 * 2; }
+  else { a_base = (const char*)p.A + lk0 * lda_b + lm0 * 2; a_bytes = (kend - kbeg) * lda_b - lm0 * 2; }
+  if constexpr (!B_KM) { b_base = (const char*)p.B + ln0 * ldb_b + lk0 * 2; b_bytes = (p.N - ln0) * ldb_b - lk0 * 2; }
+  else { b_base = (const char*)p.B + lk0 * ldb_b + ln0 * 2; b_bytes = (kend - kbeg) * ldb_b - ln0 * 2; }
   const unsigned a_rec = (unsigned)(a_bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : a_bytes);
   const unsigned b_rec = (unsigned)(b_bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : b_bytes);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, a_rec, 0x00020000);

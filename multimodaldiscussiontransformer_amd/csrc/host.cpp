@@ -160,3 +160,67 @@ extern "C" int mdt_pack_structure(int B, const int64_t* n_nodes, const int64_t* 
                                   int spatial_pos_max, float* attn_bias, int32_t* spatial_pos, int64_t* in_degree) {
   return mdt_pack_structure_ud(B, n_nodes, parents, nullptr, nmax, spatial_pos_max, attn_bias, spatial_pos, in_degree);
 }
+
+// --------------------------------------------------------------------------- image front end (host part)
+// The reference hands every image to HuggingFace's ViT image processor (experiments/hateful_discussions/datasets/
+// hateful_discussions.py:47-49, 168-184): PIL bilinear resize to 224 x 224 — for a reduction that is a triangle filter whose
+// support grows with the scale (antialiasing), run as a horizontal then a vertical pass in 22-bit fixed point with the
+// intermediate image rounded to 8 bits — then x * (1 / 255) in double rounded to float, (x - mean) / std in float.
+// mdt_resize_plan restates PIL's coefficient computation for one axis (Pillow src/libImaging/Resample.c: precompute_coeffs
+// + normalize_coeffs_8bpc, bilinear filter) so that the device passes of csrc/image.hip reproduce the resized bytes exactly;
+// mdt_image_norm_lut the 3 x 256 possible results of the rescale / normalise arithmetic.
+extern "C" int mdt_resize_plan_ksize(int in_size, int out_size) {
+  if (in_size <= 0 || out_size <= 0) return 0;
+  double filterscale = (double)in_size / (double)out_size;
+  if (filterscale < 1.0) filterscale = 1.0;
+  const double support = 1.0 * filterscale;        // bilinear: filter support 1
+  return (int)ceil(support) * 2 + 1;
+}
+
+extern "C" int mdt_resize_plan(int in_size, int out_size, int32_t* bounds, int32_t* coeffs, int ksize) {
+  MDT_CHECK_ARG(in_size > 0 && out_size > 0 && bounds && coeffs, "mdt_resize_plan: bad arguments");
+  MDT_CHECK_ARG(ksize == mdt_resize_plan_ksize(in_size, out_size), "mdt_resize_plan: ksize %d, expected %d", ksize,
+                mdt_resize_plan_ksize(in_size, out_size));
+  const double scale = (double)in_size / (double)out_size;
+  double filterscale = scale;
+  if (filterscale < 1.0) filterscale = 1.0;
+  const double support = 1.0 * filterscale;
+  const double ss = 1.0 / filterscale;
+  std::vector<double> k((size_t)ksize);
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = 0.0 + (xx + 0.5) * scale;
+    double ww = 0.0;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    for (int x = 0; x < xmax; ++x) {
+      double t = (x + xmin - center + 0.5) * ss;
+      if (t < 0.0) t = -t;
+      const double w = t < 1.0 ? 1.0 - t : 0.0;
+      k[x] = w;
+      ww += w;
+    }
+    for (int x = 0; x < xmax; ++x)
+      if (ww != 0.0) k[x] /= ww;
+    int32_t* kk = coeffs + (size_t)xx * ksize;
+    for (int x = 0; x < ksize; ++x) {
+      const double v = x < xmax ? k[x] : 0.0;
+      kk[x] = v < 0 ? (int32_t)(-0.5 + v * (double)(1 << 22)) : (int32_t)(0.5 + v * (double)(1 << 22));
+    }
+    bounds[2 * xx] = xmin;
+    bounds[2 * xx + 1] = xmax;
+  }
+  return MDT_OK;
+}
+
+extern "C" int mdt_image_norm_lut(double rescale, const float* mean3, const float* std3, float* lut) {
+  MDT_CHECK_ARG(mean3 && std3 && lut, "mdt_image_norm_lut: null pointer");
+  for (int c = 0; c < 3; ++c)
+    for (int u = 0; u < 256; ++u) {
+      const float x = (float)((double)u * rescale);        // rescale in double, ONE rounding to float
+      lut[c * 256 + u] = (x - mean3[c]) / std3[c];         // normalise in float
+    }
+  return MDT_OK;
+}

@@ -171,15 +171,27 @@ def label_variants(labels: Sequence[str]):
 
 
 def vit_pixel_values(paths: Sequence[str], size: int = 224) -> np.ndarray:
-    """ViTImageProcessor defaults of "google/vit-base-patch16-224" (:47-49, :175-180): RGB, bilinear resize to
-    size x size, scale 1/255, normalise with mean = std = 0.5 → f32[n, 3, size, size]."""
+    """ViTImageProcessor defaults of "google/vit-base-patch16-224" (:47-49, :175-180) on the host: RGB, PIL bilinear resize to
+    size x size, then the processor's arithmetic — x * (1 / 255) in double rounded once to float, (x - 0.5) / 0.5 in float —
+    through the 3 x 256 table of its possible results (``mdt_image_norm_lut``; ``a * float32(1 / 255)`` is one ulp off for
+    some bytes) → f32[n, 3, size, size], bit-identical to the processor and to the device front end."""
     from PIL import Image
+    from .. import ops
+    lut = ops.image_norm_lut().reshape(3, 256)
     out = np.empty((len(paths), 3, size, size), dtype=np.float32)
     for i, p in enumerate(paths):
-        im = Image.open(p).convert(mode="RGB").resize((size, size), resample=Image.BILINEAR)
-        a = np.asarray(im, dtype=np.float32) * (1.0 / 255.0)
-        out[i] = ((a - 0.5) / 0.5).transpose(2, 0, 1)
+        a = np.asarray(Image.open(p).convert(mode="RGB").resize((size, size), resample=Image.BILINEAR))
+        for c in range(3):
+            out[i, c] = lut[c][a[:, :, c]]
     return out
+
+
+def decoded_rgb(paths: Sequence[str]) -> list:
+    """``Image.open(p).convert(mode="RGB")`` (:175-177) as uint8 [H, W, 3] arrays at the images' OWN sizes: what the device front
+    end takes (``image_preprocess="device"``) — resize, rescale and normalise then run as ``mdt_image_preprocess`` on the GPU,
+    and the pixels cross PCIe as bytes."""
+    from PIL import Image
+    return [np.asarray(Image.open(p).convert(mode="RGB")) for p in paths]
 
 
 def default_tokenizer(name_or_vocab: str = "bert-base-uncased"):
@@ -198,11 +210,18 @@ class HatefulDiscussions:
     train-idx.txt / test-idx.txt (:93-100)."""
 
     def __init__(self, json_path: str, tokenizer: Optional[Callable] = None, max_length: int = 100, image_root: str = "",
-                 image_size: int = 224, image_loader: Optional[Callable] = None, indices: Optional[Iterable[int]] = None):
+                 image_size: int = 224, image_loader: Optional[Callable] = None, indices: Optional[Iterable[int]] = None,
+                 image_preprocess: str = "host"):
+        """``image_preprocess``: "host" — PIL resize + numpy normalise per image on the CPU, fp32 pixels in the tree (the
+        reference's way); "device" — the tree carries the decoded bytes (``images_u8``) and the packer hands them to
+        ``mdt_image_preprocess`` (bit-identical pixel values, a quarter or less of the PCIe bytes)."""
+        if image_preprocess not in ("host", "device"):
+            raise ValueError(f"image_preprocess = {image_preprocess!r} (host | device)")
         self.path = json_path
         self.tok = tokenizer if tokenizer is not None else default_tokenizer()
         self.max_length, self.image_root, self.image_size = max_length, image_root, image_size
-        self.load_images = image_loader or (lambda paths: vit_pixel_values(paths, image_size))
+        self.image_preprocess = image_preprocess
+        self.load_images = image_loader or ((lambda paths: vit_pixel_values(paths, image_size)) if image_preprocess == "host" else decoded_rgb)
         offs, off = [], 0
         with open(json_path, "rb") as f:
             for line in f:
@@ -238,6 +257,8 @@ class HatefulDiscussions:
         mask, y = label_variants([n["label"] for n in nodes])[variant]
         tree = dict(parent=parent, input_ids=ids, token_type_ids=tt, attention_mask=am, image_index=has_img, images=images,
                     y=y, y_mask=mask, ids=[n["id"] for n in nodes])
+        if self.image_preprocess == "device":
+            tree["images"], tree["images_u8"], tree["image_size"] = None, (images or []), self.image_size
         if has_repeated_ids(raw):        # rare: the reference's id-keyed hop tables are then not those of the tree
             tree["updown"] = updown_with_repeated_ids(raw, tree["ids"])
         return tree

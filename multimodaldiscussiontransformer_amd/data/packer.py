@@ -164,6 +164,7 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
     key_pad = host((B, N + 1), torch.uint8)
     deg_scatter = torch.full((B, N + 1), -1, dtype=torch.int32, pin_memory=pin)
     img_index, images, ys, y_masks = [], [], [], []
+    images_u8, u8_size = [], 224     # decoded RGB bytes at the images' own sizes (device front end, data/discussions.py)
     m = 0
     for b, t in enumerate(trees):
         n = n_nodes[b]
@@ -174,8 +175,11 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
         graph_row[m:m + n] = torch.arange(b * (N + 1) + 1, b * (N + 1) + 1 + n, dtype=torch.int32)
         key_pad[b, n + 1:] = 1
         img_index.append(np.asarray(t["image_index"], dtype=bool))
-        if t["images"] is not None and len(t["images"]):
+        if t.get("images") is not None and len(t["images"]):
             images.append(t["images"])
+        if t.get("images_u8"):
+            images_u8 += list(t["images_u8"])
+            u8_size = int(t.get("image_size", 224))
         ys.append(np.asarray(t["y"], dtype=np.float32).reshape(-1))
         # node task: which comments carry a label; graph-level (contrastive) trees have one y per tree and no mask
         y_masks.append(np.asarray(t["y_mask"], dtype=bool) if "y_mask" in t else np.zeros(n, dtype=bool))
@@ -209,6 +213,18 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
     def to(t):
         return None if t is None else t.to(device, non_blocking=non_blocking)
 
+    images_dev = None
+    if images_u8:
+        # device image front end: bytes up, mdt_image_preprocess (PIL-exact resize, 1 / 255, (x - 0.5) / 0.5) on the current stream
+        if images:
+            raise ValueError("a batch mixes host-preprocessed images (fp32) with decoded bytes (images_u8)")
+        if len(images_u8) != img_comment.numel():
+            raise ValueError("number of decoded images differs from the number of image-bearing comments")
+        if not str(device).startswith("cuda"):
+            raise ValueError("images_u8 needs the device front end (device='cuda'); on the host use image_preprocess='host'")
+        from .. import ops as _ops
+        images_dev = _ops.image_preprocess(_ops.PackedImages(images_u8, u8_size, pin=pin), device=device)
+
     in_deg_t = torch.from_numpy(in_degree)
     d32 = in_deg_t.int()
     deg_scatter[:, 1:] = torch.where(d32 > 0, d32, torch.full_like(d32, -1))
@@ -219,7 +235,7 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
         in_degree=to(in_deg_t),
         x_token_mask=to(token_mask),
         x=to(x), x_token_type_ids=to(tt), x_attention_mask=to(am),
-        x_images=to(images_t),
+        x_images=images_dev if images_dev is not None else to(images_t),
         x_image_indexes=to(torch.from_numpy(img_index)),
         y=to(torch.from_numpy(y)),
     )

@@ -13,6 +13,7 @@ import torch
 from . import _lib as L
 from ._lib import (EPI_ACCUM, EPI_ASUM, EPI_ATOMIC, EPI_AUX_GRAD, EPI_BIAS, EPI_COLSUM, EPI_DGELU, EPI_DROPOUT, EPI_GELU, EPI_MULAUX, EPI_RESIDUAL, check, dt, lib,
                    ptr, stream)
+from ._lib import MdtError
 
 __all__ = [
     "bert_embed_rows",
@@ -387,3 +388,95 @@ def dropout_mask(n, p, seed, device="cuda"):
     m = torch.empty(n, dtype=torch.uint8, device=device)
     check(lib.mdt_dropout_mask(stream(), n, float(p), int(seed), ptr(m)), "mdt_dropout_mask")
     return m
+
+
+# ------------------------------------------------------------------------------------------ image front end
+_PLAN_CACHE: dict = {}
+
+
+def resize_plan(in_size: int, out_size: int):
+    """PIL's bilinear taps of one axis (``mdt_resize_plan``, host): (bounds i32[out, 2], coeffs i32[out, k])."""
+    import numpy as np
+    key = (int(in_size), int(out_size))
+    hit = _PLAN_CACHE.get(key)
+    if hit is None:
+        k = lib.mdt_resize_plan_ksize(*key)
+        bounds = np.zeros((key[1], 2), dtype=np.int32)
+        coeffs = np.zeros((key[1], k), dtype=np.int32)
+        check(lib.mdt_resize_plan(key[0], key[1], bounds.ctypes.data, coeffs.ctypes.data, k), "mdt_resize_plan")
+        hit = _PLAN_CACHE[key] = (bounds, coeffs)
+        if len(_PLAN_CACHE) > 4096:
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+    return hit
+
+
+def image_norm_lut(rescale=1.0 / 255.0, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)):
+    import numpy as np
+    m, s_ = np.asarray(mean, dtype=np.float32), np.asarray(std, dtype=np.float32)
+    lut = np.zeros(3 * 256, dtype=np.float32)
+    check(lib.mdt_image_norm_lut(float(rescale), m.ctypes.data, s_.ctypes.data, lut.ctypes.data), "mdt_image_norm_lut")
+    return lut
+
+
+class PackedImages:
+    """Host side of ``mdt_image_preprocess``: decoded RGB images (uint8 HWC, any sizes) laid back to back in ONE pinned byte
+    buffer with the descriptor / tap tables the kernel walks.  ``upload()`` → device copies (non-blocking)."""
+
+    def __init__(self, images, out_size: int = 224, pin: bool = True):
+        import numpy as np
+        n = len(images)
+        self.n, self.out_size = n, out_size
+        desc = np.zeros((n, 8), dtype=np.int64)
+        plans, plan_off, off_of = [], 0, {}
+        pix_off = tmp_off = 0
+        for i, im in enumerate(images):
+            if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+                raise MdtError("image_preprocess takes decoded RGB images: uint8 [H, W, 3]")
+            H, W = int(im.shape[0]), int(im.shape[1])
+            offs = []
+            for size in (W, H):
+                if size not in off_of:
+                    b, c = resize_plan(size, out_size)
+                    off_of[size] = (plan_off, c.shape[1])
+                    plans += [b.reshape(-1), c.reshape(-1)]
+                    plan_off += b.size + c.size
+                offs.append(off_of[size])
+            desc[i] = (pix_off, tmp_off, H, W, offs[0][0], offs[0][1], offs[1][0], offs[1][1])
+            pix_off += H * W * 3
+            tmp_off += H * out_size * 3
+        self.max_h = int(desc[:, 2].max()) if n else 0
+        self.tmp_bytes = int(tmp_off)
+        self.pixels = torch.empty(max(pix_off, 1), dtype=torch.uint8, pin_memory=pin and torch.cuda.is_available())
+        view = self.pixels.numpy()
+        for i, im in enumerate(images):
+            o = int(desc[i, 0])
+            view[o:o + im.size] = np.ascontiguousarray(im).reshape(-1)
+        self.desc = torch.from_numpy(desc)
+        self.plan = torch.from_numpy(np.concatenate(plans) if plans else np.zeros(1, dtype=np.int32))
+
+    def upload(self, device="cuda"):
+        return (self.pixels.to(device, non_blocking=True), self.desc.to(device, non_blocking=True), self.plan.to(device, non_blocking=True))
+
+
+_LUT_DEV: dict = {}
+
+
+def image_preprocess(packed: "PackedImages", *, dtype=torch.float32, device="cuda", rescale=1.0 / 255.0, mean=(0.5, 0.5, 0.5),
+                     std=(0.5, 0.5, 0.5), return_bytes: bool = False):
+    """Decoded RGB bytes → ViT pixel tensors [n, 3, out, out] on the device (``mdt_image_preprocess``): PIL-exact bilinear resize,
+    x / 255, (x - mean) / std — the reference's ViTImageProcessor call (hateful_discussions.py:168-184) for a whole batch.
+    ``return_bytes``: also the resized uint8 images [n, out, out, 3] (tests)."""
+    n, S = packed.n, packed.out_size
+    out = torch.empty(n, 3, S, S, dtype=dtype, device=device)
+    if n == 0:
+        return (out, torch.empty(0, S, S, 3, dtype=torch.uint8, device=device)) if return_bytes else out
+    key = (float(rescale), tuple(mean), tuple(std), str(device))
+    lut = _LUT_DEV.get(key)
+    if lut is None:
+        lut = _LUT_DEV[key] = torch.from_numpy(image_norm_lut(rescale, mean, std)).to(device)
+    pix, desc, plan = packed.upload(device)
+    tmp = torch.empty(packed.tmp_bytes, dtype=torch.uint8, device=device)
+    u8 = torch.empty(n, S, S, 3, dtype=torch.uint8, device=device) if return_bytes else None
+    check(lib.mdt_image_preprocess(stream(), n, packed.max_h, ptr(pix), ptr(desc), ptr(plan), ptr(tmp), ptr(lut), dt(out), ptr(out),
+                                   ptr(u8), S), "mdt_image_preprocess")
+    return (out, u8) if return_bytes else out

@@ -2,6 +2,8 @@
 TEST INFRASTRUCTURE ONLY — see oracle/__init__.py."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from multimodaldiscussiontransformer_amd import synthetic
@@ -165,3 +167,17 @@ def contrastive_trees(hp):
         t["y"] = np.asarray([y[i]], dtype=np.float32)
         t["hard_y"] = np.asarray([hard[i]], dtype=np.float32)
     return trees
+
+
+# ----------------------------------------------------------------------------- image front end
+def pixel_value_inputs(sample_dir):
+    """Decoded RGB images of the pixel-value fixture: the three sample PNGs of tests/golden/discussions plus seeded synthetic
+    images at sizes that make PIL's resize enlarge, reduce (antialiasing: up to 11 taps) and skip an axis."""
+    from PIL import Image
+    rng = np.random.Generator(np.random.PCG64(224))
+    imgs = [np.asarray(Image.open(os.path.join(sample_dir, n + ".png")).convert(mode="RGB")) for n in "abc"]
+    for (H, W) in ((300, 500), (731, 1000), (224, 224), (97, 1023), (224, 301)):
+        base = rng.integers(0, 256, (H // 8 + 2, W // 8 + 2, 3)).astype(np.float64)      # blocky structure + noise
+        up = np.kron(base, np.ones((8, 8, 1)))[:H, :W]
+        imgs.append(np.clip(up + rng.normal(0, 20, (H, W, 3)), 0, 255).astype(np.uint8))
+    return imgs

@@ -629,6 +629,32 @@ def case_discussions():
     print("discussions", [len(o["order"]) for o in out])
 
 
+def case_pixel_values():
+    """The reference's image path (experiments/hateful_discussions/datasets/hateful_discussions.py:47-49,168-184):
+    ``extractor(images, return_tensors="pt")["pixel_values"]`` with the ViT image processor's defaults (the checkpoint name it
+    passes, google/vit-base-patch16-224, only supplies those defaults: 224 x 224 bilinear, 1 / 255, mean = std = 0.5) on
+    ``Image.open(..).convert(mode="RGB")`` inputs.  Stored (tests/golden/discussions/pixel_values.npz): the resized bytes of
+    every image and the 3 x 256 table of values the rescale / normalise arithmetic can produce; the generator asserts that
+    pixel_values == table[resized bytes] for every image, so the two together ARE the processor's output."""
+    from PIL import Image
+    from transformers import ViTImageProcessor
+    extractor = ViTImageProcessor()
+    from . import cases
+    imgs = cases.pixel_value_inputs(os.path.join(OUT, "discussions"))
+    pv = extractor([Image.fromarray(a) for a in imgs], return_tensors="pt")["pixel_values"].numpy()
+    ramp = np.arange(224 * 224, dtype=np.int64).reshape(224, 224, 1) % 256
+    ramp = np.repeat(ramp, 3, axis=2).astype(np.uint8)
+    lut_img = extractor([Image.fromarray(ramp)], return_tensors="pt", do_resize=False)["pixel_values"].numpy()[0]      # [3, 224, 224]
+    lut = np.stack([lut_img[c].reshape(-1)[:256] for c in range(3)])
+    resized = np.stack([np.asarray(Image.fromarray(a).resize((224, 224), resample=Image.BILINEAR)) for a in imgs])
+    for i in range(len(imgs)):
+        for c in range(3):
+            assert np.array_equal(pv[i, c], lut[c][resized[i, :, :, c]]), (i, c)
+    np.savez_compressed(os.path.join(OUT, "discussions", "pixel_values.npz"), resized=resized, lut=lut.astype(np.float32),
+                        sizes=np.asarray([a.shape[:2] for a in imgs], dtype=np.int64), checksum=np.asarray([float(pv.astype(np.float64).sum())]))
+    print("pixel_values", pv.shape, float(pv.min()), float(pv.max()))
+
+
 def case_fusion_layer(mods):
     from transformers import BertConfig, ViTConfig
     from transformers.models.bert.modeling_bert import BertLayer
@@ -687,6 +713,7 @@ def main():
     updown = load_updown_functions()
     if only and only[0] == "discussions":
         case_discussions()
+        case_pixel_values()
         return
     if only and only[0] == "keys":
         case_state_dict_keys(mods, models)
@@ -709,6 +736,7 @@ def main():
     print("contrastive done")
     case_state_dict_keys(mods, models)
     case_discussions()
+    case_pixel_values()
 
 
 if __name__ == "__main__":
