@@ -40,7 +40,7 @@ def agg(kind, counter):
             continue
         n = r["Kernel_Name"]
         key = "other"
-        for k in ("gemm_bf16_w4p", "gemm_bf16_pp256p", "gemm_bf16_pp256", "gemm_bf16_tile128", "attn_bwd_v4", "attn_bwd_v3", "attn_fwd_v2", "layernorm_bwd",
+        for k in ("gemm_bf16_w4s", "gemm_bf16_w4p", "gemm_bf16_pp256p", "gemm_bf16_pp256", "gemm_bf16_tile128", "attn_bwd_v4", "attn_bwd_v3", "attn_fwd_v2", "layernorm_bwd",
                   "layernorm_fwd", "colsum"):
             if k in n:
                 key = k
@@ -61,7 +61,7 @@ for k in fe:
     fb, wb = fe[k][1] * 1024 * 2, wr[k][1] * 1024
     out["kernels"][k] = dict(launches=n, fetch_bytes_per_launch=round(fb / n), write_bytes_per_launch=round(wb / n),
                              bytes_per_launch=round((fb + wb) / n))
-g = [out["kernels"][k] for k in ("gemm_bf16_w4p", "gemm_bf16_pp256p", "gemm_bf16_pp256", "gemm_bf16_tile128") if k in out["kernels"]]
+g = [out["kernels"][k] for k in ("gemm_bf16_w4s", "gemm_bf16_w4p", "gemm_bf16_pp256p", "gemm_bf16_pp256", "gemm_bf16_tile128") if k in out["kernels"]]
 tl = sum(x["launches"] for x in g)
 sys.path.insert(0, root)
 try:
