@@ -189,7 +189,7 @@ class MultiGraphormerGraphEncoder(nn.Module):
         the hidden states of padded positions) and ragged (``ragged_tokens``, default: only valid tokens own rows;
         logits and gradients are unchanged, see data/packer.py RaggedText)."""
         nb = self.num_bottle_neck
-        ragged = bool(self.ragged_tokens)
+        ragged = bool(self.ragged_tokens) and not self.needs_long_attention(pb)
         key = ("enc_idx", nb, ragged)
         if key in pb.extras:
             return pb.extras[key]
@@ -314,7 +314,7 @@ class MultiGraphormerGraphEncoder(nn.Module):
             # bottle_neck[:, 0, :] = x[mask]  (:425)
             E.rows_mix(tape, text, x, M, alpha=1.0, beta=0.0, d_idx=ix["bn0_rows"], s_idx=pb.graph_row)
             prune = None
-            if prune_last and st == F - 2:
+            if prune_last and st == F - 2 and not self.needs_long_attention(pb):
                 # after the last fusion layer only bottleneck token 0 (graph copy-back, head) and [CLS] (head) of each
                 # comment are ever read: compute just those rows there
                 prune, rows = self._prune_indices(pb, ix)
@@ -337,19 +337,25 @@ class MultiGraphormerGraphEncoder(nn.Module):
 
     MAX_ATTENTION_TOKENS = 272      # one workgroup holds a whole (sequence, head) on chip (csrc/attention*.hip)
 
-    def check_sequence_limits(self, pb: PackedBatch):
-        """Text (nb + L tokens) and image (nb + P tokens) sequences run on the single-pass attention kernels, at most 272
-        tokens: a batch beyond that is refused HERE, with the numbers, instead of failing inside forward after half the
-        step was enqueued.  Discussion TREES may be of any size, as in the reference (--max-nodes 10000 is declared and
-        never enforced, tasks/task.py:41-44): graph attention over more than 271 comments takes the key-chunked kernels
-        of csrc/attention_long.hip (same numbers, plain fp32 FMAs instead of MFMA)."""
+    def needs_long_attention(self, pb: PackedBatch) -> bool:
+        """Text (nb + L tokens) and image (nb + P tokens) sequences run on the single-pass MFMA attention kernels up to 272
+        tokens — every configuration of BASELINE.json (L = 100; ViT-B/16: 201, ViT-L/14: 261).  The reference's encoders take
+        more (BERT up to max_position_embeddings = 512 tokens, multigraphormer_graph_encoder.py:236-245; a 384-px ViT has 577):
+        such a batch runs in the reference's padded layout with every row of the last fusion layer computed (the key-chunked
+        kernels of csrc/attention_long.hip take key masks, not ragged offsets or a query limit) — same numbers, plain fp32
+        FMAs instead of MFMA.  Discussion TREES may be of any size either way (--max-nodes 10000 is declared and never
+        enforced, tasks/task.py:41-44): graph attention over more than 271 comments takes the same kernels."""
         lim = self.MAX_ATTENTION_TOKENS
         nb = self.num_bottle_neck
         npatch = (self.vit_config["image_size"] // self.vit_config["patch"]) ** 2 + 1
-        if nb + pb.L > lim:
-            raise ValueError(f"{nb} bottleneck + {pb.L} text tokens per comment exceed the {lim}-token attention limit")
-        if pb.I > 0 and nb + npatch > lim:
-            raise ValueError(f"{nb} bottleneck + {npatch} image tokens exceed the {lim}-token attention limit")
+        return nb + pb.L > lim or (pb.I > 0 and nb + npatch > lim)
+
+    def check_sequence_limits(self, pb: PackedBatch):
+        """What the encoders cannot take at all is refused HERE, with the numbers, before anything is enqueued: comments longer
+        than BERT's position table (HF raises an index error there)."""
+        max_pos = self.text_model.embeddings.position_embeddings.weight.shape[0]
+        if pb.L > max_pos:
+            raise ValueError(f"{pb.L} text tokens per comment exceed the BERT position table ({max_pos})")
 
     def _prune_indices(self, pb: PackedBatch, ix):
         key = ("prune_idx", self.num_bottle_neck, bool(self.ragged_tokens))
