@@ -193,6 +193,10 @@ int mdt_attention_bwd(void* stream, const mdt_attn_bwd_args* a);
  * recomputed from the qkv buffer and the log-sum-exp mdt_attention_fwd wrote (same args struct; out / dropout fields are
  * not read).  Masked keys give 0. */
 int mdt_attention_mean_probs(void* stream, const mdt_attn_fwd_args* a, float* out);
+/* Per-head weights of the same attention (need_head_weights / before_softmax of modules/multihead_attention.py:91-102,186-214):
+ * out fp32 [nseq, H, S, S] = softmax probabilities before dropout (raw_scores = 0; needs a->lse) or the scores
+ * q k^T * scale + bias with masked keys at -inf (raw_scores = 1).  Dense sequences only. */
+int mdt_attention_head_weights(void* stream, const mdt_attn_fwd_args* a, int raw_scores, float* out);
 
 /* Materialise the [nseq,H,S,S] structural bias (API parity with GraphAttnBias.forward,
  * modules/graphormer_layers.py:86-110); the fused encoder path never calls this. */

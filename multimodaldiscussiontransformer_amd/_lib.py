@@ -58,6 +58,7 @@ _SIGS = {
     "mdt_attention_fwd": ([_vp, C.POINTER(AttnFwdArgs)], _i),
     "mdt_attention_bwd": ([_vp, C.POINTER(AttnBwdArgs)], _i),
     "mdt_attention_mean_probs": ([_vp, C.POINTER(AttnFwdArgs), _vp], _i),
+    "mdt_attention_head_weights": ([_vp, C.POINTER(AttnFwdArgs), _i, _vp], _i),
     "mdt_graph_attn_bias": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
     "mdt_row_axpby": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _f,
                        _vp, _i64, _vp, _i64, _i64, _i64, _f, _i], _i),

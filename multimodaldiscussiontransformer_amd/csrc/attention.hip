@@ -691,6 +691,53 @@ extern "C" int mdt_attention_mean_probs(void* stream, const mdt_attn_fwd_args* a
   return check_launch("attention_mean_probs");
 }
 
+// Per-head attention weights (modules/multihead_attention.py:91-102,186-214: ``need_head_weights`` — the softmax probabilities
+// BEFORE dropout of every head — and ``before_softmax`` — the raw scores q k^T * scale + bias with masked keys at -inf),
+// recomputed like the head average above: one thread per (sequence, head, query, key); fp32 output [nseq, H, S, S].
+// Module-level API only (nothing in mDT asks for them).
+template <typename T, bool RAW>
+__global__ __launch_bounds__(256) void attn_head_weights_kernel(mdt_attn_fwd_args a, float* out) {
+  const int S = a.S, H = a.H, hd = a.hd;
+  const int64_t n = (int64_t)a.nseq * H * S * S;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int key = (int)(i % S), q = (int)((i / S) % S), h = (int)((i / ((int64_t)S * S)) % H), seq = (int)(i / ((int64_t)S * S * H));
+    const T* qrow = (const T*)a.qkv + ((int64_t)seq * a.seq_stride + (int64_t)q * a.pos_stride) * a.ld_qkv + h * hd;
+    const T* krow = (const T*)a.qkv + ((int64_t)seq * a.seq_stride + (int64_t)key * a.pos_stride) * a.ld_qkv + (int64_t)H * hd + h * hd;
+    BiasCtx bc{seq, h, S, H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
+    float v = key_only_bias<T>(bc, key);
+    if (v == 0.f) {
+      float dot = 0.f;
+      for (int d = 0; d < hd; ++d) dot += to_f32(qrow[d]) * to_f32(krow[d]);
+      v = dot * a.scale + (a.attn_bias ? pair_bias<T, true>(bc, q, key) : pair_bias<T, false>(bc, q, key));
+    }
+    if constexpr (RAW) {
+      out[i] = v;
+    } else {
+      const float l = a.lse[((int64_t)seq * H + h) * S + q];
+      out[i] = (v == -INFINITY || l == -INFINITY) ? 0.f : __expf(v - l);
+    }
+  }
+}
+
+extern "C" int mdt_attention_head_weights(void* stream, const mdt_attn_fwd_args* a, int raw_scores, float* out) {
+  MDT_CHECK_ARG(a && out, "attention_head_weights: null args");
+  if (a->nseq == 0) return MDT_OK;
+  if (int e = check_args(*a)) return e;
+  MDT_CHECK_ARG(!a->seq_offsets, "attention_head_weights: ragged sequences are not supported (module-level API only)");
+  MDT_CHECK_ARG(raw_scores || a->lse, "attention_head_weights: probabilities need the forward's log-sum-exp");
+  const int64_t n = (int64_t)a->nseq * a->H * a->S * a->S;
+  const int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == MDT_F32) {
+    if (raw_scores) hipLaunchKernelGGL((attn_head_weights_kernel<float, true>), grid, 256, 0, st, *a, out);
+    else hipLaunchKernelGGL((attn_head_weights_kernel<float, false>), grid, 256, 0, st, *a, out);
+  } else {
+    if (raw_scores) hipLaunchKernelGGL((attn_head_weights_kernel<bf16_t, true>), grid, 256, 0, st, *a, out);
+    else hipLaunchKernelGGL((attn_head_weights_kernel<bf16_t, false>), grid, 256, 0, st, *a, out);
+  }
+  return check_launch("attention_head_weights");
+}
+
 extern "C" int mdt_graph_attn_bias(void* stream, int dtype, int nseq, int S, int H, const float* attn_bias,
                                    const int32_t* spatial_pos, const void* sp_table, const void* virt, float* out) {
   MDT_CHECK_ARG(attn_bias && spatial_pos && sp_table && virt && out, "graph_attn_bias: null pointer");

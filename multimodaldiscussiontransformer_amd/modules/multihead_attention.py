@@ -81,19 +81,34 @@ class MultiheadAttention(QKVFusedMixin, nn.Module):
                 before_softmax: bool = False, need_head_weights: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
         """Input shape: Time x Batch x Channel.  ``key`` / ``value`` are ignored exactly as in the
         reference (:134-136 project ``query`` three times)."""
-        if need_head_weights or before_softmax or attn_mask is not None:
-            raise NotImplementedError("per-head weights / raw scores / attn_mask are never used by mDT and unsupported here")
         tgt_len, bsz, embed_dim = query.size()
         assert embed_dim == self.embed_dim, f"query dim {embed_dim} != {self.embed_dim}"
+        if need_head_weights:
+            need_weights = True                      # :91-102
         if key_padding_mask is not None and key_padding_mask.dim() == 0:
             key_padding_mask = None
         if key_padding_mask is not None:
             assert key_padding_mask.size(0) == bsz and key_padding_mask.size(1) == tgt_len
         x2 = query.contiguous().view(tgt_len * bsz, embed_dim)
         kpad = None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
+        if attn_mask is not None:
+            # an additive [tgt, src] mask shared by every sequence and head (:176-178): folded into the dense bias
+            am = attn_mask.float().reshape(1, 1, tgt_len, tgt_len)
+            attn_bias = am.expand(bsz, self.num_heads, tgt_len, tgt_len) if attn_bias is None else \
+                attn_bias.reshape(bsz, self.num_heads, tgt_len, tgt_len).float() + am
         inputs = [x2]
         if attn_bias is not None:
             inputs.append(attn_bias.reshape(bsz, self.num_heads, tgt_len, tgt_len).float().contiguous())
+        from .. import ops
+        if before_softmax:
+            # (:189-190) the raw scores and v, no attention output: q k^T * scaling + bias, masked keys at -inf,
+            # [bsz * heads, tgt, src] and [bsz * heads, src, head_dim].  Detached (nothing in mDT asks for them).
+            with torch.no_grad():
+                qkv = ops.gemm(x2, self.qkv_weight.data, bias=None if self.qkv_bias is None else self.qkv_bias.data)
+                sc = ops.attention_head_weights(qkv, None, bsz, tgt_len, self.num_heads, raw_scores=True, seq_stride=1, pos_stride=bsz,
+                                                scale=self.scaling, dense_bias=inputs[1] if len(inputs) > 1 else None, key_pad=kpad)
+                v = qkv[:, 2 * embed_dim:].reshape(tgt_len, bsz * self.num_heads, self.head_dim).transpose(0, 1)
+            return sc.view(bsz * self.num_heads, tgt_len, tgt_len).to(query.dtype), v
 
         stash = {} if need_weights else None
 
@@ -106,12 +121,14 @@ class MultiheadAttention(QKVFusedMixin, nn.Module):
         (out,) = E.run_tape(run, inputs, params)
         weights = None
         if need_weights:
-            # head-averaged softmax probabilities BEFORE dropout, [bsz, tgt_len, src_len] (:205-214, the reference's
-            # default); recomputed from q, k and the forward's log-sum-exp — the fused kernel never stores them.  Returned
-            # detached: nothing in mDT differentiates through them.
-            from .. import ops
+            # softmax probabilities BEFORE dropout (:205-214): head-averaged [bsz, tgt_len, src_len] (the reference's default) or,
+            # with need_head_weights, per head [heads, bsz, tgt_len, src_len]; recomputed from q, k and the forward's
+            # log-sum-exp — the fused kernel never stores them.  Returned detached: nothing in mDT differentiates through them.
             kw = {k: v for k, v in stash["kw"].items() if k not in ("seq_offsets", "q_limit", "bins")}
-            weights = ops.attention_mean_probs(stash["qkv"], stash["lse"], bsz, tgt_len, self.num_heads, **kw)
+            if need_head_weights:
+                weights = ops.attention_head_weights(stash["qkv"], stash["lse"], bsz, tgt_len, self.num_heads, **kw).transpose(0, 1)
+            else:
+                weights = ops.attention_mean_probs(stash["qkv"], stash["lse"], bsz, tgt_len, self.num_heads, **kw)
         return out.view(tgt_len, bsz, embed_dim), weights
 
     def apply_sparse_mask(self, attn_weights, tgt_len: int, src_len: int, bsz: int):

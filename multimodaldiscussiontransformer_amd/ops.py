@@ -179,6 +179,22 @@ def attention_mean_probs(qkv, lse, nseq, S, H, *, seq_stride=None, pos_stride=1,
     return out
 
 
+def attention_head_weights(qkv, lse, nseq, S, H, *, raw_scores=False, seq_stride=None, pos_stride=1, scale=None, key_mask=None,
+                           dense_bias=None, attn_bias=None, spatial_pos=None, sp_table=None, virt=None, key_pad=None):
+    """Per-head attention weights f32[nseq, H, S, S]: the softmax probabilities before dropout (needs the forward's ``lse``), or
+    with ``raw_scores`` the scores q k^T * scale + bias with masked keys at -inf (``lse`` may be None)."""
+    D = qkv.shape[1] // 3
+    hd = D // H
+    out = torch.empty(nseq, H, S, S, dtype=torch.float32, device=qkv.device)
+    if lse is None:            # raw scores do not read it; the argument check wants a buffer
+        assert raw_scores
+        lse = torch.empty(nseq * H * S, dtype=torch.float32, device=qkv.device)
+    a = _attn_args(qkv, qkv, lse, nseq, S, H, hd, S if seq_stride is None else seq_stride, pos_stride,
+                   hd ** -0.5 if scale is None else scale, key_mask, dense_bias, attn_bias, spatial_pos, sp_table, virt, key_pad)
+    check(lib.mdt_attention_head_weights(stream(), C.byref(a), 1 if raw_scores else 0, ptr(out)), "mdt_attention_head_weights")
+    return out
+
+
 def attention_bwd(dout, qkv, out, lse, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None, key_mask=None,
                   dense_bias=None, attn_bias=None, spatial_pos=None, sp_table=None, virt=None, key_pad=None,
                   want_dense_dbias=False, d_sp_table=None, d_virt=None, drop_p=0.0, drop_seed=0, seq_offsets=None, q_limit=0,
