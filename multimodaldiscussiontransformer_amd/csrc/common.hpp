@@ -48,9 +48,6 @@ struct Switches {
   int gemm_diag;             // MDT_GEMM_DIAG      (0: none)
   char gemm_tile[16];        // MDT_GEMM_TILE      ("" unset)
   bool gemm_no_pp;           // MDT_GEMM_NO_PP
-  int gemm_phase;            // MDT_GEMM_PHASE     (0: workgroups of an XCD start in phase; G >= 2: G contiguous slot groups start 1/G of a tile period apart)
-  int gemm_phase_step;       // MDT_GEMM_PHASE_STEP  shader cycles per 32-k step assumed by the period estimate (default 1600)
-  int gemm_phase_epi;        // MDT_GEMM_PHASE_EPI   shader cycles per tile outside the K loop assumed by the estimate (default 12000)
   int gemm_w4;               // MDT_GEMM_W4        (default 2: the 4-wave persistent kernel where it is measured faster; 0: never; 1: every persistent launch)
   bool attn_v1;              // MDT_ATTN_V1
   char attn_bwd[8];          // MDT_ATTN_BWD       ("" unset)

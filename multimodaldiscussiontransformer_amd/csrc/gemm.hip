@@ -815,7 +815,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
     const int steps = (blockIdx.x & 7) * ((nhs + 12) / 8);          // a tile period ~ nhs steps + an epilogue worth ~12
     for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(28);
   }
-  phase_delay(p);
   // Tile walk.  Static (tile_queue == NULL): v = blockIdx.x, + gridDim.x, ...  Dynamic: the first tile is blockIdx.x,
   // every later one comes from a queue — one head per XCD (virtual ids v = x + 8 j keep the XCD-aware order), other
   // XCDs' queues are raided when the own one is empty — so a CU that starts late or shares its time with another
@@ -1056,7 +1055,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int steps = (((int)blockIdx.x >> 3) / p.group_n) * ((nhs + 12) / (groups > 0 ? groups : 1));
     for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(28);
   }
-  phase_delay(p);
   int v = blockIdx.x;
   int v_next = v + (int)gridDim.x < nvt ? v + (int)gridDim.x : -1;
   Desc cur = make_desc(v);
@@ -1483,25 +1481,6 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   const bool persist = persist_ok && sizeof(TOut) == 2 && p.split_k == 1 && nhs_total >= 4 && (int)grid.x > num_cus();
   if (persist) grid.x = (unsigned)num_cus();
   p.tile_queue = nullptr;
-  p.phase_unit = 0; p.phase_j0 = 32; p.phase_w = 32;
-  if (persist && sw.gemm_phase >= 2 && (int)grid.x == 256) {
-    // G contiguous slot groups; the groups that start late are the high slots, which are also the ones the static walk
-    // hands one tile LESS when the tile count is not a multiple of the grid (workgroup b gets an extra tile iff b < r,
-    // i.e. slot j < r / 8): with G = 2 the boundary sits exactly there, and the late group's delay is paid for by the
-    // tile it does not have
-    const int G = sw.gemm_phase > 8 ? 8 : sw.gemm_phase;
-    const int nvt_ = p.tiles_m * p.tiles_n;
-    const int r_ = nvt_ % (int)grid.x;
-    const long period = (long)nhs_total * sw.gemm_phase_step + sw.gemm_phase_epi;
-    p.phase_w = (32 + G - 1) / G;
-    p.phase_j0 = p.phase_w;
-    if (G == 2) {
-      int j0 = r_ / 8;
-      if (j0 < 8 || j0 > 24) j0 = 16;
-      p.phase_j0 = j0; p.phase_w = 32;
-    }
-    p.phase_unit = (unsigned)(period / G);
-  }
   if (persist && nhs_total >= W4_NEXPL + 2) {
     // MDT_GEMM_W4: 0 off; 1 every persistent launch; 2 the launches it is measured faster on (k-contiguous operands, light
     // epilogues: plain, bias, residual, bias + dropout + residual, saved derivative + column sums — not the GELU form, not k-major operands)
@@ -1791,7 +1770,6 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   p.tile_queue = nullptr;
   p.alpha_dev = p.alpha_dev2 = nullptr;
   p.group_n = 1 << 30;   // row-major unless launch_pp256 decides otherwise
-  p.phase_unit = 0; p.phase_j0 = 32; p.phase_w = 32;
   p.epilogue |= switches().gemm_diag << 20;   // diagnostics: 1 skip stores, 2 sc1 stores, 4 skewed starts within an XCD, 8 every tile loads tile (0,0)'s panels, 64 XCDs skewed against each other, 256 row-panel groups skewed inside an XCD (4-wave kernel)
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_COLSUM) || (colsum && split_k == 1), "mdt_gemm: MDT_EPI_COLSUM needs a colsum buffer and split_k == 1");
   // (MDT_EPI_ATOMIC already implies an fp32 C; said again because the kernels compute the sums in their fp32-output form only)
@@ -1912,7 +1890,6 @@ extern "C" int mdt_gemm_fp8(void* stream, int a_format, int64_t M, int64_t N, in
   p.colsum = colsum;
   p.tiles_m = (int)((M + 255) / 256);
   p.tiles_n = (int)(N / 256);
-  p.phase_unit = 0; p.phase_j0 = 32; p.phase_w = 32;
   return a_format == 0 ? launch_pp256p_f8<1>((hipStream_t)stream, p) : launch_pp256p_f8<2>((hipStream_t)stream, p);
 }
 

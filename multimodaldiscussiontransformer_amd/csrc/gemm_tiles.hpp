@@ -24,24 +24,8 @@ struct GemmParams {
   float* colsum;
   int* tile_queue;              // persistent kernel, dynamic mode: 9 device ints (one head per XCD + finished-workgroup count), all 0 between launches
   unsigned long long* stamps;   // diagnostic (MDT_GEMM_STAMP=1): per workgroup {shader cycles, 100-MHz ticks, k-tiles} of the main loop
-  // Phase groups (persistent kernels): slot j = workgroup index inside its XCD (blockIdx.x >> 3).  Slots below phase_j0 start at
-  // once; the others wait (1 + (j - phase_j0) / phase_w) * phase_unit shader cycles first, so that the groups' epilogues (their
-  // output-store bursts) fall into the other groups' K loops.  phase_unit = 0: everybody starts at once.
-  int phase_j0, phase_w; unsigned phase_unit;
 };
 
-// The start delay of a phase group: sleep until the shader clock has advanced by `cycles` (s_sleep granules; exact length does
-// not matter — a group only has to be roughly a fraction of a tile period behind its neighbour).
-__device__ __forceinline__ void phase_delay(const GemmParams& p) {
-  if (p.phase_unit == 0) return;
-  const int j = (int)blockIdx.x >> 3;
-  if (j < p.phase_j0) return;
-  const unsigned long long wait = (unsigned long long)(1 + (j - p.phase_j0) / p.phase_w) * p.phase_unit;
-  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-}
-
-// ------------------------------------------------------------------ shared epilogue
 template <typename TIn, typename TOut>
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t row, int64_t col, float v) {
   if (row >= p.M || col >= p.N) return;

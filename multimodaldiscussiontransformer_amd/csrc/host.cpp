@@ -49,9 +49,6 @@ static void read_switches() {
   g_sw.gemm_stamp = flag("MDT_GEMM_STAMP");
   g_sw.gemm_no_spec = flag("MDT_GEMM_NO_SPEC");
   g_sw.gemm_diag = num("MDT_GEMM_DIAG", 0);
-  g_sw.gemm_phase = num("MDT_GEMM_PHASE", 0);
-  g_sw.gemm_phase_step = num("MDT_GEMM_PHASE_STEP", 1600);
-  g_sw.gemm_phase_epi = num("MDT_GEMM_PHASE_EPI", 12000);
   str("MDT_GEMM_TILE", g_sw.gemm_tile, sizeof(g_sw.gemm_tile));
   g_sw.gemm_no_pp = flag("MDT_GEMM_NO_PP");
   g_sw.gemm_w4 = num("MDT_GEMM_W4", 2);
