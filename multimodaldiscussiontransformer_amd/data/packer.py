@@ -75,6 +75,9 @@ class PackedBatch:
     n_labels: int = 0
     extras: dict = field(default_factory=dict)
     ragged: Optional["RaggedText"] = None      # valid-token packing (built on the host by pack_batch; lazily otherwise)
+    host: Optional[dict] = None                # pack_batch only: numpy copies of what the encoder's index vectors are derived from
+    #                                            (token offsets, comment of every token row, node_row, img_comment, token mask),
+    #                                            so that those vectors are built on the HOST in the packer thread, not by eager kernels
 
     @property
     def T(self):
@@ -253,6 +256,11 @@ def pack_batch(trees: List[dict], spatial_pos_max: int = 10, device="cuda", non_
         n_labels=int(label_rows.numel()),
     )
     pb.ragged = ragged_text(ids, types, tmask, device=device, non_blocking=non_blocking)   # host-side: no device sync
+    lens_np = tmask.numpy().astype(np.int64).sum(1)
+    off_np = np.zeros(M + 1, dtype=np.int64)
+    np.cumsum(lens_np, out=off_np[1:])
+    pb.host = dict(offsets=off_np, comment=np.repeat(np.arange(M, dtype=np.int64), lens_np), node_row=node_row.numpy().astype(np.int64),
+                   img_comment=img_comment.numpy().astype(np.int64), text_mask=tmask.numpy(), pin=pin, non_blocking=non_blocking)
     bd["_packed"] = pb                             # lets model(**net_input) find the CSR view
     # the same view as plain tensors / ints: a sample that is moved between devices by a generic "apply to every tensor
     # of the nested dict" (FairSeq's utils.move_to_cuda) carries these along, and packed_from_batched_data rebuilds the

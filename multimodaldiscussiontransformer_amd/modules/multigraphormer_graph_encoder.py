@@ -197,6 +197,10 @@ class MultiGraphormerGraphEncoder(nn.Module):
         M, Lq = pb.M, pb.L
         np_ = (self.vit_config["image_size"] // self.vit_config["patch"]) ** 2
         Sv = nb + np_ + 1
+        if pb.host is not None:
+            idx = self._indices_host(pb, nb, ragged, np_, Sv)
+            pb.extras[key] = idx
+            return idx
         i32 = dict(device=dev, dtype=torch.int32)
         j = torch.arange(nb, **i32)
         m_ar = torch.arange(M, **i32)
@@ -230,6 +234,58 @@ class MultiGraphormerGraphEncoder(nn.Module):
         )
         pb.extras[key] = idx
         return idx
+
+    def _indices_host(self, pb: PackedBatch, nb: int, ragged: bool, np_: int, Sv: int):
+        """The same vectors as the device arithmetic of ``_indices``, computed with numpy from the packer's host copies and
+        uploaded (pinned, non-blocking, on whatever stream is current — the prefetch thread's copy stream): a batch from
+        ``pack_batch`` costs the step no eager index kernels at all."""
+        import numpy as np
+        h = pb.host
+        dev = pb.ids.device
+        M, Lq, I = pb.M, pb.L, pb.I
+        pin = bool(h["pin"]) and dev.type == "cuda"
+
+        def up(a):
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32))
+            if pin:
+                t = t.pin_memory()
+            return t.to(dev, non_blocking=bool(h["non_blocking"]))
+
+        j = np.arange(nb, dtype=np.int64)
+        m_ar = np.arange(M, dtype=np.int64)
+        if ragged:
+            rt = get_ragged(pb)
+            off_pre = h["offsets"]
+            off_fus = off_pre + np.arange(M + 1, dtype=np.int64) * nb
+            bn0 = off_fus[:M]
+            pre2fus = np.arange(rt.rows, dtype=np.int64) + (h["comment"] + 1) * nb
+            rows_pre, rows_fus = rt.rows, rt.rows + M * nb
+            S_pre, S_fus = rt.max_len, rt.max_len + nb
+            spec_pre = dict(S=S_pre, seq_offsets=rt.offsets, bins=rt.length_bins(0) if self.length_bins else None)
+            spec_fus = dict(S=S_fus, seq_offsets=up(off_fus), bins=rt.length_bins(nb) if self.length_bins else None)
+        else:
+            St = nb + Lq
+            bn0 = m_ar * St
+            r = np.arange(M * Lq, dtype=np.int64)
+            pre2fus = (r // Lq) * St + nb + r % Lq
+            rows_pre, rows_fus = M * Lq, M * St
+            km = np.concatenate([np.ones((M, nb), dtype=np.uint8), h["text_mask"].reshape(M, Lq).astype(np.uint8)], axis=1)
+            kmt = torch.from_numpy(np.ascontiguousarray(km))
+            if pin:
+                kmt = kmt.pin_memory()
+            spec_pre = dict(S=Lq, key_mask=pb.text_mask)
+            spec_fus = dict(S=St, key_mask=kmt.to(dev, non_blocking=bool(h["non_blocking"])))
+        node_row = h["node_row"]
+        bn0_dev = up(bn0)
+        return dict(
+            ragged=ragged, Sv=Sv, P=np_ + 1, rows_pre=rows_pre, rows_fus=rows_fus, spec_pre=spec_pre, spec_fus=spec_fus,
+            pre2fus=up(pre2fus), bn0_rows=bn0_dev, cls_rows=up(bn0 + nb),
+            bn_rows_all=up((bn0[:, None] + j[None]).reshape(-1)),
+            text_row_of_node=up(np.where(node_row >= 0, bn0[np.clip(node_row, 0, None)] if M else node_row, node_row)),
+            img_text_bn_rows=up((bn0[h["img_comment"]][:, None] + j[None]).reshape(-1)),
+            vit_bn_rows=up((np.arange(I, dtype=np.int64)[:, None] * Sv + j[None]).reshape(-1)),
+            _host=dict(bn0=bn0, up=up),
+        )
 
     # ------------------------------------------------------------------ tape-level forward
     def _fwd(self, tape, pb: PackedBatch, prune_last: bool = False):
@@ -359,6 +415,14 @@ class MultiGraphormerGraphEncoder(nn.Module):
 
     def _prune_indices(self, pb: PackedBatch, ix):
         key = ("prune_idx", self.num_bottle_neck, bool(self.ragged_tokens))
+        if key not in pb.extras and "_host" in ix:
+            import numpy as np
+            hb, up = ix["_host"]["bn0"], ix["_host"]["up"]
+            m2 = np.arange(pb.M, dtype=np.int64) * 2
+            prune = dict(text_keep=up(np.stack([hb, hb + self.num_bottle_neck], axis=1).reshape(-1)),
+                         vit_keep=up(np.arange(pb.I, dtype=np.int64) * ix["Sv"]),
+                         img_bn0_compact=up(pb.host["img_comment"] * 2))
+            pb.extras[key] = (prune, dict(bn0_rows=up(m2), cls_rows=up(m2 + 1)))
         if key not in pb.extras:
             dev = pb.ids.device
             i32 = dict(device=dev, dtype=torch.int32)
