@@ -169,7 +169,8 @@ class GradientBucketer:
         bucket's closing event, finally the compute stream's ``wait_stream``) sees the reduced bytes.  (Round 2 waited
         with the compute stream current and then copied on the comm stream, which had never been ordered behind the
         collective: a race gloo's blocking wait could not show.)"""
-        ordered = self.comm_stream is not None and self._backend_is_stream_ordered()
+        import os
+        ordered = self.comm_stream is not None and self._backend_is_stream_ordered() and os.environ.get("MDT_DDP_EARLY_WAIT", "1") != "0"
         if self.wire_dtype is None:
             h = dist.all_reduce(chunk, group=self.pg, async_op=True)
             if ordered:
