@@ -77,3 +77,18 @@ def test_packed_images_layout():
     assert np.array_equal(pk.pixels.numpy()[d[1, 0]:d[1, 0] + imgs[1].size].reshape(300, 500, 3), imgs[1])
     with pytest.raises(Exception):
         ops.PackedImages([np.zeros((4, 4), dtype=np.uint8)])
+
+
+def test_image_entry_points_validate_their_arguments():
+    from multimodaldiscussiontransformer_amd import _lib as L
+    b = np.zeros((224, 2), dtype=np.int32)
+    c = np.zeros((224, 3), dtype=np.int32)
+    assert L.lib.mdt_resize_plan_ksize(56, 224) == 3 and L.lib.mdt_resize_plan_ksize(0, 224) == 0
+    assert L.lib.mdt_resize_plan(56, 224, b.ctypes.data, c.ctypes.data, 5) == -1          # wrong ksize
+    assert b"ksize" in L.lib.mdt_last_error_string()
+    assert L.lib.mdt_resize_plan(56, 224, None, c.ctypes.data, 3) == -1
+    assert L.lib.mdt_image_norm_lut(1 / 255, None, None, None) == -1
+    # device entry point: refused on the host side before any launch
+    assert L.lib.mdt_image_preprocess(None, 1, 10, None, None, None, None, None, 0, None, None, 224) == -1
+    assert b"null" in L.lib.mdt_last_error_string()
+    assert L.lib.mdt_image_preprocess(None, 0, 0, None, None, None, None, None, 0, None, None, 224) == 0    # empty batch: nothing to do
