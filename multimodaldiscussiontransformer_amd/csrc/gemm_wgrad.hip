@@ -11,7 +11,7 @@
 // prologue.  Epilogue: the four 64 x 64 blocks of a wave go through its 16-KiB LDS slot (the ring is idle by then) and leave
 // as 256-byte contiguous fp32 atomics (tile_epilogue<float>); MDT_EPI_ASUM (the bias gradient riding on the weight
 // gradient) as in the 8-wave kernel: in the workgroups of tile column 0 the two waves that hold the same A fragments take
-// four of the eight row tiles each against a B fragment of ones.
+// four of the eight row tiles each against a B fragment of ones, and the tiles_n workgroups of a row panel share the K steps.
 // Replaces the autograd of every nn.Linear weight (reference: modules/multi_graphormer_fusion_layer.py:94-96,138-146 and the
 // HF BertLayer / ViTLayer linears behind them).
 #include <utility>
@@ -126,8 +126,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   int b_next = 1, b_wr = PP_DIST % PP_NB;
   f32x4 acc[8][8];
-  // MDT_EPI_ASUM: column sums of op(A) over k in the workgroups of tile column 0
-  const bool asum = (p.epilogue & MDT_EPI_ASUM) && tn == 0;
+  // MDT_EPI_ASUM: column sums of op(A) over k.  The workgroups (tm, 0 .. tiles_n - 1) of a slab read the same A fragments, so they
+  // SHARE the work: workgroup tn takes every tiles_n-th 32-k step (its counter starts at tn and fires at 0) — four extra MFMAs in
+  // a tiles_n-th of the steps of every workgroup instead of in every step of one tile column, whose workgroups then were the
+  // slowest of the launch (measured before the split, one call: +4 % qkv, +11 % o, +7 % fc1, +5 % fc2 over the same launch
+  // without the riding sums)
+  const bool asum_on = (p.epilogue & MDT_EPI_ASUM) != 0;
+  int asum_ctr = tn;
   f32x4 accb[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) accb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -168,6 +173,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if constexpr (IS) issue_piece(sa, sb, b_wr, b);
       W4S_MF(b, 6); W4S_MF(b, 7);
     }
+    const bool asum = asum_on && asum_ctr == 0;
+    asum_ctr = asum_ctr + 1 == p.tiles_n ? 0 : asum_ctr + 1;
     if (asum) {                                   // wave-uniform: the two waves of a row half split its eight row tiles
       if (wc == 0) { W4S_PIN(0); W4S_PIN(1); W4S_PIN(2); W4S_PIN(3); W4S_MB(0, 0); W4S_MB(1, 1); W4S_MB(2, 2); W4S_MB(3, 3); }
       else { W4S_PIN(4); W4S_PIN(5); W4S_PIN(6); W4S_PIN(7); W4S_MB(0, 4); W4S_MB(1, 5); W4S_MB(2, 6); W4S_MB(3, 7); }
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef W4S_MF
 #undef W4S_MB
 #undef W4S_PIN
-  if (asum && (lane & 15) == 0) {      // every column of the ones product holds the row sum: column 0 reports it
+  if (asum_on && (lane & 15) == 0) {   // every column of the ones product holds the row sum: column 0 reports it
     const int64_t mr = m0 + wr * 128 + wc * 64 + 4 * (lane >> 4);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
