@@ -177,6 +177,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
   const int ep = p.epilogue;
   if constexpr (sizeof(TOut) == 4) {
     if (ep & MDT_EPI_ATOMIC) {
+      if (ep & (1 << 20)) return;                 // diagnostic (MDT_GEMM_DIAG=1): no output — what the atomics' tail costs a launch
       float* c = (float*)p.C + n0w + lane;
       for (int row = 0; row < 64; ++row) {
         const int64_t gr = m0w + row;
