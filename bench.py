@@ -562,9 +562,9 @@ def main():
         scal[2:6] = torch.stack([log["ncorrect"], log["num_positive_correct"], log["total_positive"],
                                  log["num_pred_positive"]]).float()
         mark("scalars")
-        dp.finish_backward(scal)
+        gscale = dp.finish_backward(scal, fold_scale=opt is not None)     # 1 / sample size rides on Adam's read of the gradients
         if opt is not None:
-            opt.step()
+            opt.step(grad_scale=gscale)
         mark("finish")
         return loss
 

@@ -204,9 +204,12 @@ class GradientBucketer:
         self.launched = b
         self.launch_log.append((a, b))
 
-    def finish(self, scalars: Optional[torch.Tensor] = None, sample_size_index: int = 1):
+    def finish(self, scalars: Optional[torch.Tensor] = None, sample_size_index: int = 1, fold_scale: bool = False):
         """End of backward: reduce what is left, wait, scale by 1 / global sample size.
-        ``scalars`` (fp32 vector: loss, sample_size, counters...) is summed over ranks in place."""
+        ``scalars`` (fp32 vector: loss, sample_size, counters...) is summed over ranks in place.
+        ``fold_scale``: do not touch the arena (a read + write of every gradient) but return the device scalar
+        1 / max(sample size, 1) for the optimiser to apply while it reads the gradients (``FusedAdam.step(grad_scale=...)``);
+        the arena then holds the SUM over samples and ranks."""
         if self.active:
             self.bucket_events = self.bucket_events[-64:]
             if self.comm_stream is not None:
@@ -229,10 +232,15 @@ class GradientBucketer:
                 chunk.copy_(wire)                            # on the current stream, which the wait above has ordered
             if self.comm_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
+        scale = None
         if scalars is not None:
-            self.flat.div_(scalars[sample_size_index].clamp(min=1.0))
+            if fold_scale:
+                scale = scalars[sample_size_index].clamp(min=1.0).reciprocal()
+            else:
+                self.flat.div_(scalars[sample_size_index].clamp(min=1.0))
         self.last_launch_log = list(self.launch_log)
         self.reset()
+        return scale
 
     def _comm_waits_for_compute(self):
         """The gradients of a bucket were written by kernels on the current stream and, with a two-stream tape, on the
@@ -289,11 +297,13 @@ class DataParallel:
         """--update-freq: call before each micro-batch's backward; overlapped all-reduce only on the last one."""
         self.bucketer.sync_this_backward = bool(last_micro_batch)
 
-    def finish_backward(self, logging_scalars: Optional[torch.Tensor] = None):
-        self.bucketer.finish(logging_scalars)
+    def finish_backward(self, logging_scalars: Optional[torch.Tensor] = None, fold_scale: bool = False):
+        """``fold_scale``: see ``GradBucketer.finish`` — returns the gradient scale to hand to the optimiser's step."""
+        scale = self.bucketer.finish(logging_scalars, fold_scale=fold_scale)
         self._steps += 1
         if not self.bucketer.layout_final:
             self.bucketer.finalize_layout()       # after the first backward: completion-ordered buckets
+        return scale
 
     def broadcast_parameters(self, src: int = 0, chunk_bytes: int = 256 << 20):
         """Rank ``src``'s parameters and buffers to everyone: a few large flat broadcasts (one per dtype and per

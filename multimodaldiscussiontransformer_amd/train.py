@@ -339,8 +339,8 @@ def main(argv=None):
             acc[1] += float(sample_size)
             acc[2:6] += torch.stack([log[k] for k in counter_keys]).float()
         scal.copy_(acc)
-        dp.finish_backward(scal)                 # all-reduce (world > 1) and divide by the global sample size
-        opt.step(lr=lr_for(upd))
+        gscale = dp.finish_backward(scal, fold_scale=True)     # all-reduce (world > 1); 1 / global sample size is applied by the optimiser
+        opt.step(lr=lr_for(upd), grad_scale=gscale)
         if upd % args.log_interval == 0 or upd == max_update:
             s = scal.tolist()                    # the only host sync, once per log interval
             m = crit_cls.compute_metrics([dict(loss=s[0], sample_size=s[1], **dict(zip(counter_keys, s[2:6])))])

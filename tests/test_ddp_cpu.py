@@ -108,6 +108,29 @@ def test_relayout_preserves_gradients_single_process():
         assert p.main_grad.data_ptr() >= flat.data_ptr()
 
 
+def test_folded_gradient_scale_equals_the_arena_divide():
+    """finish(fold_scale=True) leaves the arena holding the sum and hands back 1 / max(sample size, 1) for the optimiser:
+    sum * scale is what the unfolded path writes into the arena (1 ulp: a multiply by the reciprocal instead of a divide)."""
+    from multimodaldiscussiontransformer_amd.ddp import GradientBucketer
+    out = {}
+    for fold in (False, True):
+        params = [torch.nn.Parameter(torch.zeros(7, 3)), torch.nn.Parameter(torch.zeros(5))]
+        flat = torch.zeros(26)
+        b = GradientBucketer(params, flat)
+        torch.manual_seed(3)
+        flat.copy_(torch.randn(26))
+        scal = torch.tensor([1.5, 6.0, 0, 0, 0, 0])
+        scale = b.finish(scal, fold_scale=fold)
+        out[fold] = (flat.clone(), scale)
+    assert out[False][1] is None
+    assert float(out[True][1]) == pytest.approx(1.0 / 6.0)
+    torch.manual_seed(3)
+    assert torch.equal(out[True][0], torch.randn(26))                      # untouched
+    assert torch.allclose(out[True][0] * out[True][1], out[False][0], rtol=3e-7, atol=0)
+    b = GradientBucketer([torch.nn.Parameter(torch.zeros(2))], torch.zeros(2))
+    assert float(b.finish(torch.tensor([0.0, 0.0]), fold_scale=True)) == 1.0      # an empty batch divides by 1, as before
+
+
 def test_balance_trees_by_token_cost():
     """greedy assignment by N_i (L + nb) + I_i (P + nb).  Skewed image fractions: dealing trees round-robin
     leaves one rank with most of the image work; the balanced deal is within a few per cent."""
