@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmdt_hip.so")
-SOURCES = ["gemm.hip", "gemm_wgrad.hip", "layernorm.hip", "attention.hip", "attention_v2.hip", "attention_long.hip", "rowops.hip", "contrastive.hip", "fp8.hip", "optim.hip", "image.hip", "host.cpp"]
+SOURCES = ["gemm.hip", "gemm_wgrad.hip", "gemm_f8.hip", "layernorm.hip", "attention.hip", "attention_v2.hip", "attention_long.hip", "rowops.hip", "contrastive.hip", "fp8.hip", "optim.hip", "image.hip", "host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-ffp-contract=off"]
 # attention: keep MFMA results in VGPRs — the softmax works on the accumulators in place, and with the default
 # AGPR form the compiler spends 10-15 % of the VALU stream on v_accvgpr_read/write copies (gfx950's file is unified)
@@ -42,7 +42,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "attention_common.hpp"), os.path.join(CSRC, "gemm_tiles.hpp"),
+    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "attention_common.hpp"), os.path.join(CSRC, "gemm_tiles.hpp"), os.path.join(CSRC, "gemm_epilogue.hpp"),
                os.path.join(HERE, "..", "include", "mdt_hip.h")]
     objs, jobs = [], []
     for s in SOURCES:

@@ -48,6 +48,7 @@ struct Switches {
   int gemm_diag;             // MDT_GEMM_DIAG      (0: none)
   char gemm_tile[16];        // MDT_GEMM_TILE      ("" unset)
   bool gemm_no_pp;           // MDT_GEMM_NO_PP
+  int gemm_f8w;              // MDT_GEMM_F8W       (default 1: 8-bit GEMMs on the 16x16x128 block-MFMA kernel where it has an instantiation; 0: the 8-wave kernel)
   int gemm_w4;               // MDT_GEMM_W4        (default 2: the 4-wave persistent kernel where it is measured faster; 0: never; 1: every persistent launch)
   bool attn_v1;              // MDT_ATTN_V1
   char attn_bwd[8];          // MDT_ATTN_BWD       ("" unset)

@@ -343,5 +343,7 @@ __device__ __forceinline__ void w4_dma(__amdgpu_buffer_rsrc_t rs, char* lds, uns
 
 // 4-wave split-K kernel for fp32-accumulating launches (weight gradients), gemm_wgrad.hip
 int launch_w4s(hipStream_t st, const GemmParams& p, int ta, int tb);
+// 4-wave 8-bit kernel on the 16x16x128 block MFMA, gemm_f8.hip; -1: no instantiation for this (format, epilogue, shape)
+int launch_f8_w4(hipStream_t st, const GemmParams& p, int a_format, int n_cus);
 
 }  // namespace mdt

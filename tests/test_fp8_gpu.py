@@ -95,6 +95,52 @@ def test_gemm_fp8_epilogues_match_bf16_gemm_epilogues(ops):
     torch.testing.assert_close(cs, full.sum(0), atol=0.5, rtol=3e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(66000, 2304, 768), (70001, 3072, 768), (25700, 768, 3072), (300, 768, 1280)])
+def test_gemm_fp8_block_mfma_kernel_against_the_8_wave_kernel_and_fp32_math(ops, monkeypatch, M, N, K):
+    """The 4-wave kernel on v_mfma_f32_16x16x128_f8f6f4 (gemm_f8.hip: bias / GELU forward with its saved derivative / plain and
+    saved-derivative input gradients) against the 8-wave kernel on the 16x16x32 form (MDT_GEMM_F8W=0) on the same quantised
+    operands: the two differ only in how 128 products are summed before they join the fp32 accumulator, far below the bf16
+    rounding of the outputs — and both against fp32 math on spot rows."""
+    from multimodaldiscussiontransformer_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(21)
+    a = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    dy = (torch.randn(M, K, device="cuda", generator=g) * 0.1).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g).bfloat16()
+    saved = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    sa, sd, sw = _scale_for(a, 448.0), _scale_for(dy, 57344.0), _scale_for(w, 448.0)
+    a8, d8, w8 = ops.fp8_quantize(a, 0, scale=sa), ops.fp8_quantize(dy, 1, scale=sd), ops.fp8_quantize(w, 0, scale=sw)
+
+    def run():
+        aux = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        cs = torch.zeros(N, device="cuda")
+        outs = [ops.gemm_fp8(a8, w8, 1 / sa, 1 / sw, bias=bias),
+                ops.gemm_fp8(a8, w8, 1 / sa, 1 / sw, bias=bias, aux=aux, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD), aux,
+                ops.gemm_fp8(d8, w8, 1 / sd, 1 / sw, a_format=1),
+                ops.gemm_fp8(d8, w8, 1 / sd, 1 / sw, a_format=1, aux=saved, epilogue=ops.EPI_MULAUX, colsum=cs), cs]
+        torch.cuda.synchronize()
+        return outs
+
+    try:
+        monkeypatch.setenv("MDT_GEMM_F8W", "0"); _lib.reload_env()
+        old = run()
+        monkeypatch.setenv("MDT_GEMM_F8W", "1"); _lib.reload_env()
+        new = run()
+    finally:
+        monkeypatch.delenv("MDT_GEMM_F8W", raising=False); _lib.reload_env()
+    for name, o, n in zip(("bias", "gelu", "gelu derivative", "dgrad", "dgrad x saved", "column sums"), old, new):
+        o, n = o.float(), n.float()
+        # at most one bf16 rounding step apart where the two sums fall on either side of a rounding boundary
+        torch.testing.assert_close(n, o, atol=1e-2 * float(o.abs().max()), rtol=8e-3, msg=lambda m: f"{name}: {m}")
+        assert float((n - o).norm() / o.norm()) < 2e-3, name
+    rows = torch.randint(0, M, (1024,), device="cuda", generator=g)
+    rows[:256] = torch.arange(max(0, M - 256), max(0, M - 256) + 256, device="cuda").clamp(max=M - 1)
+    ref = (a8[rows].view(torch.float8_e4m3fn).float() @ w8.view(torch.float8_e4m3fn).float().t()) / (sa * sw) + bias.float()
+    torch.testing.assert_close(new[0][rows].float(), ref, atol=2e-2 * float(ref.abs().max()), rtol=1.6e-2)
+    refd = (d8[rows].view(torch.float8_e5m2).float() @ w8.view(torch.float8_e4m3fn).float().t()) / (sd * sw)
+    torch.testing.assert_close(new[3][rows].float(), refd, atol=2e-2 * float(refd.abs().max()), rtol=1.6e-2)
+
+
 def test_unsupported_shapes_are_refused_not_miscomputed(ops):
     from multimodaldiscussiontransformer_amd._lib import MdtError
     one = torch.ones(1, device="cuda")

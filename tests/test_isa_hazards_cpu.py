@@ -1,4 +1,4 @@
-"""Static checks on the gfx950 assembly of the 4-wave GEMM kernel (gemm_bf16_w4p): its MFMAs are asm statements, which hides
+"""Static checks on the gfx950 assembly of the 4-wave GEMM kernels (gemm_bf16_w4p, and the 8-bit gemm_f8_w4 built the same way): their MFMAs are asm statements, which hides
 them from the compiler's hazard recognizer, and three things that went wrong on the GPU because of that are visible in the
 instruction stream ("three traps").  The checks read the disassembly of the object the in-tree build produced (no GPU needed).
 
@@ -30,36 +30,39 @@ def w4_kernels(tmp_path_factory):
         pytest.skip("llvm-objdump / llvm-readelf not available")
     from multimodaldiscussiontransformer_amd import build as B
     B.build()                                           # no-op when the objects are newer than the sources
-    tmp = tmp_path_factory.mktemp("isa")
-    obj = shutil.copy(os.path.join(B.HERE, "build", "gemm.o"), tmp / "gemm.o")
-    subprocess.run([OBJDUMP, "--offloading", str(obj)], cwd=tmp, capture_output=True, text=True, check=True)   # unbundles beside it
-    co = [f for f in os.listdir(tmp) if "amdgcn" in f]
-    assert len(co) == 1, os.listdir(tmp)
-    co = str(tmp / co[0])
-    dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout.split("\n")
-    kernels, cur = {}, None
-    for l in dis:
-        m = re.match(r"^[0-9a-f]+ <(\w+)>:", l)
-        if m:
-            cur = kernels.setdefault(m.group(1), []) if "gemm_bf16_w4p" in m.group(1) else None
-            continue
-        if cur is not None:
-            t = l.split("//")[0].strip()
-            if t:
-                cur.append(t)
-    assert len(kernels) >= 10, sorted(kernels)
-    notes = subprocess.run([READELF, "--notes", co], capture_output=True, text=True, check=True).stdout
-    scratch = {}
-    for blk in re.split(r"\n\s+- \.", notes):
-        n = re.search(r"\.name:\s+(\S+)", blk) or re.search(r"^name:\s+(\S+)", blk, re.M)
-        ps = re.search(r"private_segment_fixed_size:\s+(\d+)", blk)
-        if n and ps:
-            scratch[n.group(1)] = int(ps.group(1))
+    kernels, scratch = {}, {}
+    for objname, want in (("gemm.o", "gemm_bf16_w4p"), ("gemm_f8.o", "gemm_f8_w4")):
+        tmp = tmp_path_factory.mktemp("isa")
+        obj = shutil.copy(os.path.join(B.HERE, "build", objname), tmp / objname)
+        subprocess.run([OBJDUMP, "--offloading", str(obj)], cwd=tmp, capture_output=True, text=True, check=True)   # unbundles beside it
+        co = [f for f in os.listdir(tmp) if "amdgcn" in f]
+        assert len(co) == 1, os.listdir(tmp)
+        co = str(tmp / co[0])
+        dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout.split("\n")
+        cur = None
+        for l in dis:
+            m = re.match(r"^[0-9a-f]+ <(\w+)>:", l)
+            if m:
+                cur = kernels.setdefault(m.group(1), []) if want in m.group(1) else None
+                continue
+            if cur is not None:
+                t = l.split("//")[0].strip()
+                if t:
+                    cur.append(t)
+        notes = subprocess.run([READELF, "--notes", co], capture_output=True, text=True, check=True).stdout
+        for blk in re.split(r"\n\s+- \.", notes):
+            n = re.search(r"\.name:\s+(\S+)", blk) or re.search(r"^name:\s+(\S+)", blk, re.M)
+            ps = re.search(r"private_segment_fixed_size:\s+(\d+)", blk)
+            if n and ps:
+                scratch[n.group(1)] = int(ps.group(1))
+    assert sum("gemm_bf16_w4p" in k for k in kernels) >= 10 and sum("gemm_f8_w4" in k for k in kernels) >= 4, sorted(kernels)
     return kernels, scratch
 
 
 def _specialised(name):
     m = re.search(r"ILb[01]ELb[01]ELi(\d+)E", name)      # "Lin1E" = -1 is the runtime-flag kernel
+    if m is None:
+        m = re.search(r"gemm_f8_w4ILi[01]ELi(\d+)ELi\d+E", name)      # <operand format, epilogue, further direct stores>
     return int(m.group(1)) if m else None
 
 
@@ -108,7 +111,7 @@ def test_nothing_drains_the_prefetch_ring_inside_the_k_loop(w4_kernels):
         if _specialised(name) is None:             # the runtime-flag kernel is a fallback, not a hot path
             continue
         bars = [i for i, t in enumerate(body) if t == "s_barrier"]
-        assert len(bars) > 10, name
+        assert len(bars) > (4 if "gemm_f8_w4" in name else 10), name
         lo, hi = bars[1], bars[-1]             # bars[0] is the prologue's; the last one opens the tile's last step
         for i in range(lo, hi):
             t = body[i]
@@ -125,3 +128,5 @@ def test_light_epilogues_use_no_scratch(w4_kernels):
             seen += 1
             assert b == 0, f"{name}: {b} bytes of scratch per lane"
     assert seen >= 6
+    f8 = {n: b for n, b in scratch.items() if "gemm_f8_w4" in n}
+    assert len(f8) >= 4 and all(b == 0 for b in f8.values()), f8      # every instantiation of the 8-bit kernel
