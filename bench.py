@@ -439,8 +439,9 @@ def main():
     ap.add_argument("--attention-dropout", type=float, default=0.3)
     ap.add_argument("--act-dropout", type=float, default=0.3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
-                    help="fp8 (BASELINE.json configs[4]): bf16 model with per-tensor-scaled e4m3 / e5m2 operands in the QKV and fc1 "
-                         "projections and fc2's input gradient (multimodaldiscussiontransformer_amd/fp8.py)")
+                    help="fp8 (BASELINE.json configs[4]): bf16 model with per-tensor-scaled e4m3 / e5m2 operands in the blocks' big GEMMs "
+                         "(multimodaldiscussiontransformer_amd/fp8.py; --fp8-sites picks which)")
+    ap.add_argument("--fp8-sites", default=None, help="preset (all | fast4 | grads) or comma list of fp8 sites; default: MDT_FP8_SITES or all")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
     ap.add_argument("--no-selfcheck", action="store_true", help="skip the numerics guard that runs before the warm-up")
@@ -500,7 +501,7 @@ def main():
     torch.manual_seed(1234)                      # same random-init weights on every rank
     model = GraphormerModel.build_model(base_args(args), task=None).cuda().to(dtype)
     model.train()
-    fp8_state = model.enable_fp8() if args.dtype == "fp8" else None
+    fp8_state = model.enable_fp8(sites=args.fp8_sites) if args.dtype == "fp8" else None
     dp = DataParallel(model)
     dp.broadcast_parameters()
     crit = GraphPredictionNodeCrossEntropy(None, positive_weight=1.5, negative_weight=1.0)
@@ -720,7 +721,9 @@ def main():
         }
         if fp8_state is not None:
             out["fp8"] = dict(gemm_launches_total=fp8_state.gemms, sites=len(fp8_state.sites), formats="e4m3 activations / weights, e5m2 gradients",
-                              scaling="per tensor, delayed (margin 2), device-resident", where="qkv fwd, fc1 fwd, fc2 input gradient")
+                              scaling="per tensor, delayed (margin 2), device-resident", where=",".join(fp8_state.site_names),
+                              operands_quantised_by_their_producer=fp8_state.fused_outputs,
+                              kernel="v_mfma_f32_16x16x128_f8f6f4 (gemm_f8_w4) where K % 128 == 0, else 16x16x32 fp8 (gemm_bf16_pp256p F8)")
         if dist_diag is not None:
             out["distributed"] = dict(world=world, backend=backend, comments_per_rank=per_rank_comments, variable_trees=bool(args.variable_trees),
                                       exchange_check=exchange_check, **dist_diag)

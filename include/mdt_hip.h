@@ -266,7 +266,8 @@ int mdt_node_ce(void* stream, int dtype, int64_t M, int nlab, const void* logits
 /* ------------------------------------------------------------------ fp8 operands (BASELINE.json configs[4])
  * Per-tensor-scaled OCP fp8 for the big k-contiguous GEMMs of the encoder blocks (every nn.Linear forward and, against a
  * transposed weight copy, every input gradient): C[M,N] (bf16) = epilogue((1/scale_a)(1/scale_b) * A[M,K] B[N,K]^T), A in
- * e4m3 (a_format 0: activations) or e5m2 (1: gradients), B in e4m3, fp32 accumulation on v_mfma_f32_16x16x32_{fp8,bf8}_fp8,
+ * e4m3 (a_format 0: activations) or e5m2 (1: gradients), B in e4m3, fp32 accumulation on v_mfma_f32_16x16x128_f8f6f4 (4-wave
+ * kernel, K % 128 == 0, K >= 640) or v_mfma_f32_16x16x32_{fp8,bf8}_fp8 (8-wave kernel, the rest),
  * same epilogues as mdt_gemm (bf16 store forms).  inv_scale_a / inv_scale_b are DEVICE floats (delayed scaling keeps
  * every scale on the device).  Returns MDT_ERR_UNSUPPORTED for shapes the 8-bit kernel is not built for (N % 256, K % 64,
  * K < 256, unaligned rows): the caller then stays in bf16. */
@@ -274,6 +275,17 @@ int mdt_gemm_fp8(void* stream, int a_format, int64_t M, int64_t N, int64_t K, co
                  int64_t ldb, void* C, int64_t ldc, int epilogue, const float* inv_scale_a, const float* inv_scale_b,
                  const void* bias, const void* residual, int64_t ldr, void* aux, int64_t ldaux, float drop_p,
                  uint64_t drop_seed, float* colsum);
+/* mdt_gemm_fp8 whose output ALSO leaves as fp8, for the next 8-bit GEMM to consume without a quantisation pass of its own
+ * ("quantise inside the producer": the GELU forward hands fc2 its operand, fc2's input gradient hands fc1's): q8_out u8[M, N]
+ * (rows of ld_q8 bytes) = saturate(q8_format, bf16(C) * *q8_scale), *q8_amax = max(*q8_amax, max |bf16(C)|) — bit for bit what
+ * mdt_fp8_quantize makes of C.  q8_out NULL: plain mdt_gemm_fp8.  MDT_ERR_UNSUPPORTED when no kernel writes the copy for this
+ * epilogue / shape (only the block-MFMA kernel does, for bias + GELU + saved derivative → e4m3 and saved-derivative multiply +
+ * column sums → e5m2): the caller then quantises C itself. */
+int mdt_gemm_fp8_q8(void* stream, int a_format, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                    int64_t ldb, void* C, int64_t ldc, int epilogue, const float* inv_scale_a, const float* inv_scale_b,
+                    const void* bias, const void* residual, int64_t ldr, void* aux, int64_t ldaux, float drop_p,
+                    uint64_t drop_seed, float* colsum, void* q8_out, int64_t ld_q8, int q8_format, const float* q8_scale,
+                    float* q8_amax);
 /* dst u8[rows, cols] = saturate_fp8(src * *scale_dev) (fmt 0: e4m3, |x| <= 448; 1: e5m2, |x| <= 57344; scale_dev NULL: 1);
  * *amax_dev = max(*amax_dev, max |src|) (NULL: not tracked) — the input of the next step's scale. */
 int mdt_fp8_quantize(void* stream, int src_dtype, int fmt, int64_t rows, int64_t cols, const void* src, int64_t ld_src,

@@ -73,6 +73,8 @@ _SIGS = {
     "mdt_node_ce": ([_vp, _i, _i64, _i, _vp, _vp, _vp, _f, _f, _i, _f, _vp, _vp, _vp], _i),
     "mdt_gemm_fp8": ([_vp, _i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _f,
                       C.c_uint64, _vp], _i),
+    "mdt_gemm_fp8_q8": ([_vp, _i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _f,
+                         C.c_uint64, _vp, _vp, _i64, _i, _vp, _vp], _i),
     "mdt_fp8_quantize": ([_vp, _i, _i, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp], _i),
     "mdt_fp8_scale_update": ([_vp, _i, _vp, _vp, _vp, _vp, _f], _i),
     "mdt_contrastive_loss_workspace_bytes": ([_i, _i], C.c_size_t),

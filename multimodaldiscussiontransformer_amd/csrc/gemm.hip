@@ -1586,6 +1586,15 @@ extern "C" int mdt_gemm_fp8(void* stream, int a_format, int64_t M, int64_t N, in
                             const void* B, int64_t ldb, void* C, int64_t ldc, int epilogue, const float* inv_scale_a,
                             const float* inv_scale_b, const void* bias, const void* residual, int64_t ldr, void* aux,
                             int64_t ldaux, float drop_p, uint64_t drop_seed, float* colsum) {
+  return mdt_gemm_fp8_q8(stream, a_format, M, N, K, A, lda, B, ldb, C, ldc, epilogue, inv_scale_a, inv_scale_b, bias, residual, ldr,
+                         aux, ldaux, drop_p, drop_seed, colsum, nullptr, 0, 0, nullptr, nullptr);
+}
+
+extern "C" int mdt_gemm_fp8_q8(void* stream, int a_format, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                               const void* B, int64_t ldb, void* C, int64_t ldc, int epilogue, const float* inv_scale_a,
+                               const float* inv_scale_b, const void* bias, const void* residual, int64_t ldr, void* aux,
+                               int64_t ldaux, float drop_p, uint64_t drop_seed, float* colsum, void* q8_out, int64_t ld_q8,
+                               int q8_format, const float* q8_scale, float* q8_amax) {
   MDT_CHECK_ARG(a_format == 0 || a_format == 1, "mdt_gemm_fp8: a_format %d (0 = e4m3, 1 = e5m2)", a_format);
   MDT_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "mdt_gemm_fp8: negative shape");
   if (M == 0 || N == 0) return MDT_OK;
@@ -1612,6 +1621,11 @@ extern "C" int mdt_gemm_fp8(void* stream, int a_format, int64_t M, int64_t N, in
   p.colsum = colsum;
   p.tiles_m = (int)((M + 255) / 256);
   p.tiles_n = (int)(N / 256);
+  if (q8_out) {
+    MDT_CHECK_ARG(q8_format == 0 || q8_format == 1, "mdt_gemm_fp8_q8: q8_format %d (0 = e4m3, 1 = e5m2)", q8_format);
+    MDT_CHECK_ARG(q8_scale && q8_amax && ld_q8 >= N, "mdt_gemm_fp8_q8: the fp8 output needs its scale, its maximum slot and rows of at least N bytes");
+    p.q8_out = q8_out; p.ld_q8 = ld_q8; p.q8_fmt = q8_format; p.q8_scale = q8_scale; p.q8_amax = q8_amax;
+  }
   if (switches().gemm_f8w) {
     GemmParams q = p;
     q.tile_queue = nullptr;
@@ -1623,6 +1637,8 @@ extern "C" int mdt_gemm_fp8(void* stream, int a_format, int64_t M, int64_t N, in
     const int r = launch_f8_w4((hipStream_t)stream, q, a_format, num_cus());
     if (r != -1) return r;
   }
+  // only the block-MFMA kernel writes the fp8 copy (and only for the epilogues a training step asks it for): the caller quantises the bf16 output itself
+  if (q8_out) MDT_UNSUPPORTED("mdt_gemm_fp8_q8: no kernel writes an fp8 copy for epilogue %d, K = %lld (MDT_GEMM_F8W=%d)", epilogue, (long long)K, switches().gemm_f8w);
   return a_format == 0 ? launch_pp256p_f8<1>((hipStream_t)stream, p) : launch_pp256p_f8<2>((hipStream_t)stream, p);
 }
 

@@ -39,7 +39,8 @@ template <int NJP>
 struct EpiPre { bf16x8 bias[NJP]; bf16x8 pre[8]; };
 // C (stores), X (saved-derivative stores), R (the tensor the epilogue reads: saved derivative / residual / C): descriptors based
 // at the tile's origin, one 32-bit per-lane offset each, row tile and column pair as immediate offsets
-struct EpiBuf { __amdgpu_buffer_rsrc_t rsC, rsX, rsR; unsigned voffC, voffX, voffR; int ldc16, ldx16, ldr16; };
+struct EpiBuf { __amdgpu_buffer_rsrc_t rsC, rsX, rsR; unsigned voffC, voffX, voffR; int ldc16, ldx16, ldr16;
+                __amdgpu_buffer_rsrc_t rsQ; unsigned voffQ; int ldq16; float q_scale; float* q_amax; };   // Q8 epilogues: the fp8 copy of the output (1 byte per element), its scale, the lane's running |out| maximum
 // A 16-byte buffer store whose data registers may be rewritten right behind it.  hipcc (ROCm 7.2) takes a MUBUF store with
 // an SGPR soffset to be free of the "store of more than 8 bytes, then VALU write of its data registers" hazard and puts the
 // next VALU write directly behind it; on gfx950 that store then wrote the NEW contents of its second dword for the last lanes
@@ -103,7 +104,7 @@ __device__ __forceinline__ void epi_prefetch(const GemmParams& p, int lane, int6
 // PEND kernels store through buffer descriptors based at the tile's origin (EpiBuf): rows past M fall outside the
 // descriptor and are dropped by its bounds check, so there is no per-row-group branch and — what the 4-wave kernel's
 // vmcnt arithmetic needs — the NUMBER of stores a wave issues per tile is a constant.
-template <int NJP, int EPK = -1, bool PEND = false, bool EPF = false, int PROWS = EPI_PEND_ROWS>   // PROWS: row tiles handed back by a PEND epilogue; NJP pairs of 16-column tiles per wave: 2 (128x64 blocks) or 4 (128x128 blocks)
+template <int NJP, int EPK = -1, bool PEND = false, bool EPF = false, int PROWS = EPI_PEND_ROWS, int Q8 = 0>   // Q8: 1 / 2 = the output also leaves as e4m3 / e5m2 (EpiBuf::rsQ);   // PROWS: row tiles handed back by a PEND epilogue; NJP pairs of 16-column tiles per wave: 2 (128x64 blocks) or 4 (128x128 blocks)
 __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc)[8][2 * NJP], int lane, int64_t m0w, int64_t n0w,
                                                 bf16x8* pend = nullptr, const EpiPre<NJP>* pf = nullptr, const EpiBuf* eb = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -257,6 +258,32 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+      if constexpr (Q8 != 0) {
+        // the fp8 copy of the ROUNDED output with the stand-alone quantiser's arithmetic (fp8.hip): what the consumer would
+        // have made of the bf16 tensor itself, bit for bit on finite values.  Kept to four VALU operations per element — in a
+        // kernel with one wave per SIMD nothing hides the epilogue — so a NaN is not singled out here: it stays visible in
+        // the bf16 output (and the loss), the running maximum ignores it, the fp8 copy clamps it.
+        constexpr float FMAX = Q8 == 1 ? 448.0f : 57344.0f;
+        float q[8];
+        float m8 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x0 = (float)o[e];
+          m8 = fmaxf(m8, fabsf(x0));
+          q[e] = __builtin_amdgcn_fmed3f(x0 * eb->q_scale, -FMAX, FMAX);
+        }
+        *eb->q_amax = live ? fmaxf(*eb->q_amax, m8) : *eb->q_amax;
+        int w0 = 0, w1 = 0;
+        if constexpr (Q8 == 1) {
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w0, true);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w1, true);
+        } else {
+          w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], w0, true);
+          w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q[4], q[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q[6], q[7], w1, true);
+        }
+        typedef __attribute__((ext_vector_type(2))) int i32x2_;
+        __builtin_amdgcn_raw_buffer_store_b64(i32x2_{w0, w1}, eb->rsQ, eb->voffQ, i * eb->ldq16 + jp * 32, 0);
+      }
       if constexpr (PEND) {
         if constexpr (i >= 8 - PROWS) pend[(i - (8 - PROWS)) * NJP + jp] = o;
         else epi_store16(__builtin_bit_cast(i32x4, o), eb->rsC, eb->voffC, i * eb->ldc16 + jp * 64);
@@ -290,13 +317,22 @@ __device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc
     rows(I0{}); rows(I1{}); rows(I2{}); rows(I3{}); rows(I4{}); rows(I5{}); rows(I6{}); rows(I7{});
   }
   if (ep & MDT_EPI_COLSUM) {   // the 16 lanes of a row group hold 16 rows of the same columns
+    int c2 = c, g2 = g;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (PEND && Q8 != 0) {   // the lane number once more: with the fp8 copy's registers on top it is carried across the row groups in
+      int z = 0;                       // scratch, and the reload's s_waitcnt vmcnt(0) then waits for every store the epilogue has issued
+      asm volatile("" : "+v"(z));
+      const int l2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z));
+      c2 = l2 & 15; g2 = l2 >> 4;
+    }
+#endif
 #pragma unroll
     for (int jp = 0; jp < NJP; ++jp)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float s_ = row16_sum_dpp(cs[jp][e]);
         // uniform 64-bit base + 32-bit lane offset: the per-lane 64-bit column numbers otherwise live through the whole K loop
-        if (c == 0) atomicAdd(p.colsum + n0w + (32 * jp + 16 * (g & 1) + 8 * (g >> 1) + e), s_);
+        if (c2 == 0) atomicAdd(p.colsum + n0w + (32 * jp + 16 * (g2 & 1) + 8 * (g2 >> 1) + e), s_);
       }
   }
 }

@@ -39,23 +39,17 @@ namespace mdt {
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
-constexpr int F8W_PEND_ROWS = 4;                       // row tiles whose outputs wait in registers
-constexpr int F8W_NPEND = 4 * F8W_PEND_ROWS;           // ... = pending 16-byte vectors per lane
-constexpr int F8W_SPS = 4;                             // pending vectors leaving per step
-constexpr int F8W_NST = F8W_NPEND / F8W_SPS;           // steps that carry pending stores
-constexpr int F8W_DS = 32 - F8W_NPEND;                 // direct stores of an epilogue
-constexpr int f8w_st(int s) { return s >= 0 && s < F8W_NST ? F8W_SPS : 0; }
-// vector-memory operations that may still be in flight at the barrier of step s, where the stage requested in pass 1 of step
-// s - 1 must have landed: the 8 pieces and the stores of pass 0 of step s
-constexpr int f8w_budget(int s) { return 8 + f8w_st(s); }
+constexpr int F8W_MAX_PEND_ROWS = 4;                   // row tiles whose outputs wait in registers (PR, per instantiation: at most)
+constexpr int F8W_SPS = 4;                             // pending vectors leaving per step = one row tile: PR steps carry pending stores
 
 template <class F, int... S>
 __device__ __forceinline__ void f8w_unroll(F&& f, std::integer_sequence<int, S...>) { (f(std::integral_constant<int, S>{}), ...); }
 
-template <int FA, int EPK = -1, int AUXDS = 0>        // AUXDS: further direct stores of an epilogue (the GELU forward's second output)
+template <int FA, int EPK = -1, int AUXDS = 0, int Q8 = 0, int PR = F8W_MAX_PEND_ROWS>   // PR: pending row tiles; AUXDS: further direct stores of an epilogue (the GELU forward's second output, the fp8 copy); Q8: 1 / 2 = the output also leaves as e4m3 / e5m2
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_f8_w4(GemmParams p_in) {
   constexpr int PP_NB = 5;
   constexpr int BM = 256, BN = 256, A_BYTES = BM * 64;
+  constexpr int F8W_PEND_ROWS = PR, F8W_NPEND = 4 * PR, F8W_NST = PR, F8W_DS = 32 - F8W_NPEND;   // pending vectors, steps that carry them, direct stores of an epilogue
   extern __shared__ __attribute__((aligned(16))) char smem[];
   GemmParams p = p_in;
   p.alpha = *p_in.alpha_dev * *p_in.alpha_dev2;
@@ -148,8 +142,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int i = 0; i < 4; ++i) fb[i] = frag(laneB, i, 0, 1);
   int b0 = 0;                                       // ring buffer of the current pair's first stage
   f32x4 acc[8][8];
+  float q_amax = 0.f;                               // Q8: this lane's running maximum of |output| over all its tiles
+  const float q_scale = Q8 != 0 ? *p.q8_scale : 1.0f;
 
   constexpr bool PEND = EPK >= 0;
+  constexpr bool EPF_LATE = EPK == (MDT_EPI_BIAS | MDT_EPI_RESIDUAL | MDT_EPI_DROPOUT);
   bf16x8 pend[F8W_NPEND];
 #pragma unroll
   for (int i = 0; i < F8W_NPEND; ++i) pend[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -224,7 +221,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // (younger than the pieces it waits for).  vmcnt is a 6-bit counter: a budget beyond 63 is 63 (waits a little early).
       f8w_unroll([&](auto sc) __attribute__((always_inline)) {
         constexpr int S = decltype(sc)::value;
-        constexpr int nw_ = f8w_budget(S) + (S == 0 ? F8W_DS + AUXDS : 0);
+        // in flight at the barrier of step S, where the stage requested in pass 1 of step S - 1 must have landed: the 8 pieces and the
+        // stores of pass 0 of step S (+ the epilogue's direct stores at a tile's first barrier)
+        constexpr int nw_ = 8 + F8W_SPS + (S == 0 ? F8W_DS + AUXDS : 0);
         constexpr int nw = nw_ < 63 ? nw_ : 63;
         run_step(std::integral_constant<bool, S == 0>{}, F8W_I(nw), F8W_I(S * F8W_SPS), T_{}, S);
       }, std::make_integer_sequence<int, F8W_NST>{});
@@ -249,10 +248,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       constexpr int PK = epi_pre_kind<EPK>();
       if constexpr (PK == 1) { eb.rsR = desc_of(p.aux, p.ldaux); eb.voffR = voff_of(p.ldaux); eb.ldr16 = (int)(p.ldaux * 32); }
       if constexpr (PK == 2) { eb.rsR = desc_of(p.residual, p.ldr); eb.voffR = voff_of(p.ldr); eb.ldr16 = (int)(p.ldr * 32); }
-      // what the epilogue reads first is requested before the last step (older than its LDS-DMA pieces)
-      epi_prefetch<4, EPK, true>(p, lane, cur.m0 + wr * 128, cur.n0 + wc * 128, epf, &eb);
+      if constexpr (Q8 != 0) {                      // one byte per element: a lane's 8 columns are 8 bytes, a column pair 32
+        const int64_t bytes = (p.M - cur.m0) * p.ld_q8 - cur.n0;
+        eb.rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.q8_out + cur.m0 * p.ld_q8 + cur.n0), 0,
+                                                   (unsigned)(bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : bytes), 0x00020000);
+        eb.voffQ = (unsigned)((wr * 128 + c_lane) * p.ld_q8 + (wc * 128 + 16 * (g_lane & 1) + 8 * (g_lane >> 1)));
+        eb.ldq16 = (int)(p.ld_q8 * 16);
+        eb.q_scale = q_scale;
+        eb.q_amax = &q_amax;
+      }
+      // what the epilogue reads first is requested before the last step (older than its LDS-DMA pieces) — except where those 48
+      // registers on top of the step's 128 fragment registers end up in scratch (bias + dropout + residual: the reload's
+      // s_waitcnt vmcnt(0) inside the epilogue then waits for every store issued so far): there it is requested behind the step
+      if constexpr (!EPF_LATE) epi_prefetch<4, EPK, true>(p, lane, cur.m0 + wr * 128, cur.n0 + wc * 128, epf, &eb);
     }
     run_step(F_{}, F8W_I(8), F8W_I(-1), F_{}, nsp - 1);
+    if constexpr (PEND && EPF_LATE) epi_prefetch<4, EPK, true>(p, lane, cur.m0 + wr * 128, cur.n0 + wc * 128, epf, &eb);
 #if defined(__HIP_DEVICE_COMPILE__)
     // asm MFMAs: the wait states before a VALU may read their results by hand, every accumulator re-defined behind them
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < 8; ++i)
       asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7]));
 #endif
-    direct_epilogue<4, EPK, PEND, PEND, F8W_PEND_ROWS>(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 128, pend, &epf, &eb);
+    direct_epilogue<4, EPK, PEND, PEND, F8W_PEND_ROWS, Q8>(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 128, pend, &epf, &eb);
     {                                             // the next tile's first pair landed before the last step's barrier / during its pass 1
       const int b1 = ring(b0, 1);
 #pragma unroll
@@ -285,6 +296,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     has_next = v_next >= 0;
     nxt = has_next ? make_desc(v_next) : null_desc(cur);
   }
+  if constexpr (Q8 != 0) {          // one atomic per wave and launch (non-negative floats order like their bit patterns)
+    const float m = wave_max(q_amax);
+    if (lane == 0 && m > 0.f) atomicMax((int*)p.q8_amax, __float_as_int(m));
+  }
 #undef F8W_MF
 #undef F8W_I
 }
@@ -293,13 +308,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 int launch_f8_w4(hipStream_t st, const GemmParams& p_in, int a_format, int n_cus) {
   GemmParams p = p_in;
   const int nsp = (int)(p.K / 128);
-  if (p.K % 128 != 0 || nsp < F8W_NST + 1) return -1;
+  if (p.K % 128 != 0 || nsp < F8W_MAX_PEND_ROWS + 1) return -1;
   const int nvt = p.tiles_m * p.tiles_n;
   dim3 grid((unsigned)(nvt < n_cus ? nvt : n_cus), 1, 1);
   const size_t lds = (size_t)5 * PP_STAGE;
-#define LF8W(FA_, E_, X_)                                                                                    \
+#define LF8W(FA_, E_, X_, Q_, PR_)                                                                           \
   {                                                                                                          \
-    auto kern = gemm_f8_w4<FA_, E_, X_>;                                                                     \
+    auto kern = gemm_f8_w4<FA_, E_, X_, Q_, PR_>;                                                                                       \
     static bool attr_set = false;                                                                            \
     if (!attr_set) {                                                                                         \
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
@@ -312,14 +327,21 @@ int launch_f8_w4(hipStream_t st, const GemmParams& p_in, int a_format, int n_cus
     hipLaunchKernelGGL(kern, grid, 256, lds, st, p);                                                         \
     return check_launch("gemm_f8_w4");                                                                       \
   }
-  constexpr int E_BIAS = MDT_EPI_BIAS, E_FC1 = MDT_EPI_BIAS | MDT_EPI_GELU | MDT_EPI_AUX_GRAD, E_DFC2 = MDT_EPI_MULAUX | MDT_EPI_COLSUM;
+  constexpr int E_BIAS = MDT_EPI_BIAS, E_FC1 = MDT_EPI_BIAS | MDT_EPI_GELU | MDT_EPI_AUX_GRAD, E_DFC2 = MDT_EPI_MULAUX | MDT_EPI_COLSUM,
+                E_DENSE = MDT_EPI_BIAS | MDT_EPI_RESIDUAL | MDT_EPI_DROPOUT, E_RES = MDT_EPI_RESIDUAL;
   const int e = p.epilogue;
+  const bool q8 = p.q8_out != nullptr;
+  if (q8 && !(p.q8_scale && p.q8_amax && p.ld_q8 % 8 == 0 && ((uintptr_t)p.q8_out & 7) == 0)) return -1;
   if (a_format == 0) {
-    if (e == E_BIAS) LF8W(0, E_BIAS, 0)
-    if (e == E_FC1 && p.aux) LF8W(0, E_FC1, 32)
+    if (e == E_BIAS && !q8) LF8W(0, E_BIAS, 0, 0, 4)
+    if (e == E_DENSE && !q8) LF8W(0, E_DENSE, 0, 0, 4)
+    if (e == E_FC1 && p.aux && !q8) LF8W(0, E_FC1, 32, 0, 4)
+    if (e == E_FC1 && p.aux && q8 && p.q8_fmt == 0) LF8W(0, E_FC1, 64, 1, 4)
   } else {
-    if (e == 0) LF8W(1, 0, 0)
-    if (e == E_DFC2) LF8W(1, E_DFC2, 0)
+    if (e == 0 && !q8) LF8W(1, 0, 0, 0, 4)
+    if (e == E_RES && !q8) LF8W(1, E_RES, 0, 0, 4)
+    if (e == E_DFC2 && !q8) LF8W(1, E_DFC2, 0, 0, 4)
+    if (e == E_DFC2 && q8 && p.q8_fmt == 1) LF8W(1, E_DFC2, 32, 2, 4)
   }
 #undef LF8W
   return -1;

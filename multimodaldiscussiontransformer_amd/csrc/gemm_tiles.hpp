@@ -24,6 +24,9 @@ struct GemmParams {
   float* colsum;
   int* tile_queue;              // persistent kernel, dynamic mode: 9 device ints (one head per XCD + finished-workgroup count), all 0 between launches
   unsigned long long* stamps;   // diagnostic (MDT_GEMM_STAMP=1): per workgroup {shader cycles, 100-MHz ticks, k-tiles} of the main loop
+  // 8-bit kernel only (gemm_f8.hip): the output ALSO leaves as fp8 for the next 8-bit GEMM — q8_out u8[M, N] = saturate(fmt,
+  // bf16(out) * *q8_scale), *q8_amax = max(*q8_amax, max |bf16(out)|): exactly what mdt_fp8_quantize would make of the bf16 output
+  void* q8_out = nullptr; int64_t ld_q8 = 0; const float* q8_scale = nullptr; float* q8_amax = nullptr; int q8_fmt = 0;
 };
 
 template <typename TIn, typename TOut>

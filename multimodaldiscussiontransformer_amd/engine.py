@@ -395,10 +395,13 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         t = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xk, drop_p=p_hidden, drop_seed=s_o)
         a, m1, r1 = ops.layernorm_fwd(t, P.ln1_w.data, P.ln1_b.data, eps)
         u = torch.empty(a.shape[0], P.fc1_w.shape[0], dtype=a.dtype, device=a.device)
-        h = lin8(a, P.fc1_w, "fc1", bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act)
+        h, h8 = lin8(a, P.fc1_w, "fc1", bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act,
+                     q8_site=("fc2", id(P.fc2_w))) or (None, None)
         if h is None:
             h = ops.gemm(a, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act)
-        y = ops.gemm(h, P.fc2_w.data, bias=P.fc2_b.data, residual=a, drop_p=p_hidden, drop_seed=s_f2)
+        y = lin8(h, P.fc2_w, "fc2", x8=h8, bias=P.fc2_b.data, residual=a, drop_p=p_hidden, drop_seed=s_f2)   # 8-bit when fc1 handed over the quantised h
+        if y is None:
+            y = ops.gemm(h, P.fc2_w.data, bias=P.fc2_b.data, residual=a, drop_p=p_hidden, drop_seed=s_f2)
         out, m2, r2 = ops.layernorm_fwd(y, P.ln2_w.data, P.ln2_b.data, eps)
     else:
         n1, m1, r1 = ops.layernorm_fwd(xd, P.ln1_w.data, P.ln1_b.data, eps)
@@ -410,10 +413,13 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         hmid = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xk, drop_p=p_hidden, drop_seed=s_o)
         n2, m2, r2 = ops.layernorm_fwd(hmid, P.ln2_w.data, P.ln2_b.data, eps)
         u = torch.empty(n2.shape[0], P.fc1_w.shape[0], dtype=n2.dtype, device=n2.device)
-        f = lin8(n2, P.fc1_w, "fc1", bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act)
+        f, f8q = lin8(n2, P.fc1_w, "fc1", bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act,
+                      q8_site=("fc2", id(P.fc2_w))) or (None, None)
         if f is None:
             f = ops.gemm(n2, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act)
-        out = ops.gemm(f, P.fc2_w.data, bias=P.fc2_b.data, residual=hmid, drop_p=p_hidden, drop_seed=s_f2)
+        out = lin8(f, P.fc2_w, "fc2", x8=f8q, bias=P.fc2_b.data, residual=hmid, drop_p=p_hidden, drop_seed=s_f2)
+        if out is None:
+            out = ops.gemm(f, P.fc2_w.data, bias=P.fc2_b.data, residual=hmid, drop_p=p_hidden, drop_seed=s_f2)
     o = Var(out)
 
     def hdrop(g, seed):
@@ -441,13 +447,15 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         dy, dyd = _ln_bwd_dense(tape, g, y, P.ln2_w, P.ln2_b, m2, r2, None if ride else P.fc2_b, p_hidden, s_f2)
         wgrad(tape, dyd, h, P.fc2_w, P.fc2_b if ride else None)
         gb1 = tape.pgrad(P.fc1_b)           # fc1 bias gradient = colsum(du): fused into the GEMM epilogue
-        du = lin8(dyd, P.fc2_w, "d_fc2", transposed_weight=True, grad=True, aux=u, epilogue=ops.EPI_MULAUX,
-                  colsum=None if gb1 is None else gb1.view(-1))
+        du, du8 = lin8(dyd, P.fc2_w, "d_fc2", transposed_weight=True, grad=True, aux=u, epilogue=ops.EPI_MULAUX,
+                       colsum=None if gb1 is None else gb1.view(-1), q8_site=("d_fc1", id(P.fc1_w)), q8_grad=True) or (None, None)
         if du is None:
             du = dgrad(dyd, P.fc2_w, aux=u, epilogue=ops.EPI_MULAUX,
                           colsum=None if gb1 is None else gb1.view(-1))
         wgrad(tape, du, a, P.fc1_w, None)
-        da = dgrad(du, P.fc1_w, residual=dy)
+        da = lin8(du, P.fc1_w, "d_fc1", transposed_weight=True, grad=True, x8=du8, residual=dy)      # 8-bit when the GEMM above handed over the quantised du
+        if da is None:
+            da = dgrad(du, P.fc1_w, residual=dy)
         dt_, dtd = _ln_bwd_dense(tape, da, t, P.ln1_w, P.ln1_b, m1, r1, None if ride else P.o_b, p_hidden, s_o)
         wgrad(tape, dtd, ctx, P.o_w, P.o_b if ride else None)
         dctx = ops.gemm(dtd, P.o_w.data, trans_b=True)
@@ -466,13 +474,15 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         gd = hdrop(g, s_f2)
         wgrad(tape, gd, f, P.fc2_w, P.fc2_b)
         gb1 = tape.pgrad(P.fc1_b)
-        du = lin8(gd, P.fc2_w, "d_fc2", transposed_weight=True, grad=True, aux=u, epilogue=ops.EPI_MULAUX,
-                  colsum=None if gb1 is None else gb1.view(-1))
+        du, du8 = lin8(gd, P.fc2_w, "d_fc2", transposed_weight=True, grad=True, aux=u, epilogue=ops.EPI_MULAUX,
+                       colsum=None if gb1 is None else gb1.view(-1), q8_site=("d_fc1", id(P.fc1_w)), q8_grad=True) or (None, None)
         if du is None:
             du = dgrad(gd, P.fc2_w, aux=u, epilogue=ops.EPI_MULAUX,
                           colsum=None if gb1 is None else gb1.view(-1))
         wgrad(tape, du, n2, P.fc1_w, None)
-        dn2 = dgrad(du, P.fc1_w)
+        dn2 = lin8(du, P.fc1_w, "d_fc1", transposed_weight=True, grad=True, x8=du8)
+        if dn2 is None:
+            dn2 = dgrad(du, P.fc1_w)
         ride = _WGRAD_ASUM and dyd_rides(g)
         dh, dhd = _ln_bwd_dense(tape, dn2, hmid, P.ln2_w, P.ln2_b, m2, r2, None if ride else P.o_b, p_hidden, s_o, add=g)
         wgrad(tape, dhd, ctx, P.o_w, P.o_b if ride else None)

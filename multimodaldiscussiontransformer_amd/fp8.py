@@ -7,6 +7,12 @@ projection and fc2 forward (narrow N, or a 4 D-wide activation to quantise) lose
 in bf16, as do all weight gradients (fp32 accumulation into the gradient arena) — fusing the quantisation into the
 producing kernels (LayerNorm, attention, GELU epilogue) is what would bring those in.
 
+Since round 3 the 8-bit GEMMs with K a multiple of 128 run on the block MFMA v_mfma_f32_16x16x128_f8f6f4 (csrc/gemm_f8.hip: twice
+the bf16 MFMA rate), and two of them hand their OUTPUT to the next GEMM already quantised, from their own epilogue
+(``q8_site``): the GELU forward writes fc2's e4m3 operand, fc2's input gradient writes fc1's e5m2 operand.  That makes "fc2"
+(forward, K = 4 D) and "d_fc1" (input gradient, K = 4 D) 8-bit sites without a quantisation pass of their own; they are taken only
+when the producer delivered the copy (otherwise bf16, as before).
+
 Scaling: per tensor.  Activations / gradients: DELAYED — a step quantises with the scale derived from the |x| maximum
 the previous step measured at the same site (fmax / (amax * margin), margin 2 = one binade of headroom), the quantiser
 records this step's maximum, and one launch at the end of backward turns all maxima into the next scales.  Nothing ever
@@ -27,12 +33,35 @@ import os
 MARGIN = 2.0
 # which GEMMs take the 8-bit kernel: any of "qkv", "fc1", "d_fc2" (MDT_FP8_SITES=fc1,d_fc2 leaves the QKV projection in bf16:
 # the softmax amplifies errors of q and k, see DESIGN.md for the measured trade)
-SITES = tuple(x for x in os.environ.get("MDT_FP8_SITES", "qkv,fc1,d_fc2").split(",") if x)
+# "fc2" / "d_fc1": only with the operand quantised by the producing GEMM's epilogue (fc1 forward / fc2's input gradient)
+# Presets (Fp8State(sites=...), model.enable_fp8(sites=...), MDT_FP8_SITES): measured on MI355X, mDT-base step / the C2 and C4
+# fixtures of tests/test_fp8_gpu.py (hash weights, logits spanning +-0.6) — speed over bf16 in one call, logits |err|, worst
+# parameter-gradient relative L2:
+#   "all"    qkv,fc1,fc2,d_fc2,d_fc1   +9...10 %   0.14 / 0.20   0.48     every big GEMM of the blocks but the output projection
+#   "fast4"  qkv,fc1,d_fc2,d_fc1       +7 %        0.13 / 0.12   0.43
+#   "grads"  d_fc2,d_fc1               +3 %        0.010 (the bf16 level)  0.16   8-bit only where the loss cannot see it
+PRESETS = {"all": "qkv,fc1,fc2,d_fc2,d_fc1", "fast4": "qkv,fc1,d_fc2,d_fc1", "grads": "d_fc2,d_fc1"}
+
+
+def parse_sites(spec) -> tuple:
+    if spec is None:
+        spec = os.environ.get("MDT_FP8_SITES", "all")
+    if not isinstance(spec, str):
+        return tuple(spec)
+    return tuple(x for x in PRESETS.get(spec, spec).split(",") if x)
+
+
+SITES = parse_sites(None)
+FED_BY_PRODUCER = ("fc2", "d_fc1")
+# MDT_FP8_FUSED_Q=0: the producers do not write the copies and those two sites quantise their operand with a pass of their own —
+# the same arithmetic in two launches (tests: both routes give the same bytes; tools: what the fusion is worth)
+FUSED_Q = os.environ.get("MDT_FP8_FUSED_Q", "1") != "0"
 
 
 class Fp8State:
-    def __init__(self, device, capacity: int = 8192):
+    def __init__(self, device, capacity: int = 8192, sites=None):
         self.device = torch.device(device)
+        self.site_names = SITES if sites is None else parse_sites(sites)      # which GEMMs take the 8-bit kernel
         self.scale = torch.ones(capacity, dtype=torch.float32, device=self.device)
         self.inv = torch.ones(capacity, dtype=torch.float32, device=self.device)
         self.amax = torch.zeros(capacity, dtype=torch.float32, device=self.device)
@@ -41,6 +70,8 @@ class Fp8State:
         self.weights: Dict[tuple, Tuple[torch.Tensor, int, int]] = {}
         self.weights_version = 0
         self.gemms = 0                      # launches that took the 8-bit kernel (diagnostics / tests)
+        self.fused_outputs = 0              # ... of which also wrote the next GEMM's operand
+        self.no_q8: set = set()             # consumer sites whose producer has no kernel that writes the copy (asked once)
 
     # -- sites -------------------------------------------------------------------------
     def _site(self, key, fmt) -> Tuple[int, bool]:
@@ -62,6 +93,16 @@ class Fp8State:
             self.scale[i] = ops.FP8_MAX[fmt] / (a * MARGIN)
             self.inv[i] = (a * MARGIN) / ops.FP8_MAX[fmt]
         return ops.fp8_quantize(x, fmt, scale=self.scale[i:i + 1], amax=self.amax[i:i + 1]), self.inv[i:i + 1]
+
+    def observe(self, x: torch.Tensor, key, fmt=ops.FP8_E4M3) -> bool:
+        """Make ``key`` a site whose first scale comes from ``x`` (no quantisation): the producer of x writes the fp8 copy from
+        the next step on.  → True when the site is new."""
+        i, new = self._site(key, fmt)
+        if new:
+            a = x.detach().abs().max().float().clamp_(min=1e-30)
+            self.scale[i] = ops.FP8_MAX[fmt] / (a * MARGIN)
+            self.inv[i] = (a * MARGIN) / ops.FP8_MAX[fmt]
+        return new
 
     def weight(self, w: torch.nn.Parameter, transposed: bool = False):
         """e4m3 copy of a weight ([N, K], or its transpose for dX = dY W), cached until the optimiser steps."""
@@ -94,18 +135,40 @@ class Fp8State:
     def eligible(rows: int, n_out: int, k: int) -> bool:
         return n_out % 256 == 0 and k % 64 == 0 and k >= 256 and rows >= 256
 
-    def linear(self, x: torch.Tensor, w: torch.nn.Parameter, site, *, transposed_weight=False, grad=False, **kw) -> Optional[torch.Tensor]:
+    def linear(self, x: torch.Tensor, w: torch.nn.Parameter, site, *, transposed_weight=False, grad=False, x8=None, q8_site=None,
+               q8_grad=False, **kw):
         """x[M, K] @ W^T (W [N, K]; ``transposed_weight``: x[M, N] @ W, the input gradient) through the 8-bit kernel,
-        or None when the shape is not one it is built for (the caller then runs the bf16 GEMM)."""
+        or None when the shape is not one it is built for (the caller then runs the bf16 GEMM).
+        ``x8``: (u8 tensor, inv-scale view) — x already quantised by the kernel that produced it.
+        ``q8_site``: the site of the GEMM that will consume the OUTPUT: the result is then (out, (out8, inv-scale view)), the
+        second part None when the copy could not be made here (consumer site not known yet, no kernel for it)."""
         n_out = w.shape[1] if transposed_weight else w.shape[0]
         k = w.shape[0] if transposed_weight else w.shape[1]
-        if site[0] not in SITES or x.dtype != torch.bfloat16 or not self.eligible(x.shape[0], n_out, k):
+        if site[0] not in self.site_names or x.dtype != torch.bfloat16 or not self.eligible(x.shape[0], n_out, k):
             return None
         fmt = ops.FP8_E5M2 if grad else ops.FP8_E4M3
-        x8, inv_x = self.quantize(x, site, fmt)
+        if x8 is not None:
+            x8, inv_x = x8
+        elif site[0] in FED_BY_PRODUCER and (self.observe(x, site, fmt) or FUSED_Q):
+            return None                          # first sight (known from now on: the producer writes the copy next time), or no copy came
+        else:
+            x8, inv_x = self.quantize(x, site, fmt)
         w8, inv_w = self.weight(w, transposed_weight)
         self.gemms += 1
-        return ops.gemm_fp8(x8, w8, inv_x, inv_w, a_format=fmt, **kw)
+        if q8_site is None:
+            return ops.gemm_fp8(x8, w8, inv_x, inv_w, a_format=fmt, **kw)
+        j = self.sites.get(q8_site)
+        if j is not None and FUSED_Q and q8_site[0] in self.site_names and q8_site not in self.no_q8:
+            from ._lib import MdtError
+            out8 = torch.empty(x.shape[0], n_out, dtype=torch.uint8, device=x.device)
+            try:
+                out = ops.gemm_fp8(x8, w8, inv_x, inv_w, a_format=fmt, q8_out=out8, q8_format=ops.FP8_E5M2 if q8_grad else ops.FP8_E4M3,
+                                   q8_scale=self.scale[j:j + 1], q8_amax=self.amax[j:j + 1], **kw)
+                self.fused_outputs += 1
+                return out, (out8, self.inv[j:j + 1])
+            except MdtError:
+                self.no_q8.add(q8_site)          # e.g. MDT_GEMM_F8W=0: nothing writes the copy; do not ask again
+        return ops.gemm_fp8(x8, w8, inv_x, inv_w, a_format=fmt, **kw), None
 
 
 # the active state (None: bf16 everywhere).  Set by GraphormerModel.enable_fp8(); read by engine.transformer_block.

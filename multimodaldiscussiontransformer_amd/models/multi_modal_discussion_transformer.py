@@ -127,11 +127,12 @@ class GraphormerModel(FairseqEncoderModel):
     def zero_main_grads(self):
         self.main_grad_flat.zero_()
 
-    def enable_fp8(self, on: bool = True):
+    def enable_fp8(self, on: bool = True, sites=None):
         """BASELINE.json configs[4]: per-tensor-scaled fp8 operands (e4m3 activations / weights, e5m2 gradients, delayed
-        scaling) for the encoder blocks' QKV and fc1 projections and fc2's input gradient (fp8.py says why those)."""
+        scaling) for the encoder blocks' big GEMMs.  ``sites``: a preset of fp8.PRESETS ("all" — the default —, "fast4",
+        "grads") or a comma list of site names (fp8.py says which GEMMs and what each choice costs in accuracy)."""
         from .. import fp8
-        fp8.ACTIVE = fp8.Fp8State(next(self.parameters()).device) if on else None
+        fp8.ACTIVE = fp8.Fp8State(next(self.parameters()).device, sites=sites) if on else None
         return fp8.ACTIVE
 
 

@@ -356,8 +356,11 @@ def fp8_scale_update(amax, scale, inv_scale, fmt_max, margin=1.0):
 
 
 def gemm_fp8(a8: torch.Tensor, b8: torch.Tensor, inv_scale_a: torch.Tensor, inv_scale_b: torch.Tensor, *, a_format: int = FP8_E4M3,
-             out: Optional[torch.Tensor] = None, bias=None, residual=None, aux=None, epilogue=0, drop_p=0.0, drop_seed=0, colsum=None):
-    """out[M, N] (bf16) = epilogue(inv_scale_a * inv_scale_b * a8 @ b8^T); a8 u8[M, K] (e4m3 / e5m2), b8 u8[N, K] (e4m3)."""
+             out: Optional[torch.Tensor] = None, bias=None, residual=None, aux=None, epilogue=0, drop_p=0.0, drop_seed=0, colsum=None,
+             q8_out: Optional[torch.Tensor] = None, q8_format: int = FP8_E4M3, q8_scale=None, q8_amax=None):
+    """out[M, N] (bf16) = epilogue(inv_scale_a * inv_scale_b * a8 @ b8^T); a8 u8[M, K] (e4m3 / e5m2), b8 u8[N, K] (e4m3).
+    ``q8_out`` u8[M, N]: also the fp8 copy of ``out`` (= fp8_quantize(out, q8_format, q8_scale, q8_amax)), written by the GEMM's
+    own epilogue; raises MdtError (unsupported) where no kernel does that."""
     M, K = a8.shape
     N = b8.shape[0]
     assert b8.shape[1] == K and a8.dtype == torch.uint8 and b8.dtype == torch.uint8
@@ -371,6 +374,13 @@ def gemm_fp8(a8: torch.Tensor, b8: torch.Tensor, inv_scale_a: torch.Tensor, inv_
         epilogue |= EPI_DROPOUT
     if colsum is not None:
         epilogue |= EPI_COLSUM
+    if q8_out is not None:
+        assert q8_out.dtype == torch.uint8 and q8_out.shape == (M, N)
+        check(lib.mdt_gemm_fp8_q8(stream(), int(a_format), M, N, K, ptr(a8), _2d(a8), ptr(b8), _2d(b8), ptr(out), _2d(out), epilogue,
+                                  ptr(inv_scale_a), ptr(inv_scale_b), ptr(bias), ptr(residual), _2d(residual) if residual is not None else 0,
+                                  ptr(aux), _2d(aux) if aux is not None else 0, float(drop_p), int(drop_seed), ptr(colsum),
+                                  ptr(q8_out), _2d(q8_out), int(q8_format), ptr(q8_scale), ptr(q8_amax)), "mdt_gemm_fp8_q8")
+        return out
     check(lib.mdt_gemm_fp8(stream(), int(a_format), M, N, K, ptr(a8), _2d(a8), ptr(b8), _2d(b8), ptr(out), _2d(out), epilogue,
                            ptr(inv_scale_a), ptr(inv_scale_b), ptr(bias), ptr(residual), _2d(residual) if residual is not None else 0,
                            ptr(aux), _2d(aux) if aux is not None else 0, float(drop_p), int(drop_seed), ptr(colsum)), "mdt_gemm_fp8")

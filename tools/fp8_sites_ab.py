@@ -38,6 +38,29 @@ sites = [
     ("fc2 dgrad (x saved + colsum)", 3072, lambda: ops.gemm(dy, w2t.t().contiguous(), trans_b=True, aux=saved, epilogue=ops.EPI_MULAUX, colsum=cs),
      lambda: ops.gemm_fp8(d8, q["2"][0], 1 / sd, q["2"][1], a_format=1, aux=saved, epilogue=ops.EPI_MULAUX, colsum=cs)),
 ]
+# round 3: the K = 4 D sites fed by their producers, and what writing the fp8 copy costs the producers
+h = r(M, 3072)
+w2, b2, resid = r(768, 3072) * 0.03, r(768), r(M, 768)
+w1t = r(768, 3072) * 0.05                      # fc1's weight transposed: the k-contiguous B operand of dX = dU W1
+du = r(M, 3072) * 0.1
+sh, sdu = sc(h, 448.0), sc(du, 57344.0)
+h8, du8 = ops.fp8_quantize(h, 0, scale=sh), ops.fp8_quantize(du, 1, scale=sdu)
+q["2f"] = (ops.fp8_quantize(w2, 0, scale=sc(w2, 448.0)), 1 / sc(w2, 448.0))
+q["1t"] = (ops.fp8_quantize(w1t, 0, scale=sc(w1t, 448.0)), 1 / sc(w1t, 448.0))
+out8 = torch.empty(M, 3072, device="cuda", dtype=torch.uint8)
+amax = torch.zeros(1, device="cuda")
+sites += [
+    ("fc2 fwd K3072 (bias+drop+res)", 768 * 4, lambda: ops.gemm(h, w2, bias=b2, residual=resid, drop_p=0.1, drop_seed=5),
+     lambda: ops.gemm_fp8(h8, q["2f"][0], 1 / sh, q["2f"][1], bias=b2, residual=resid, drop_p=0.1, drop_seed=5)),
+    ("fc1 dgrad K3072 (res)", 768 * 4, lambda: ops.gemm(du, w1t.t().contiguous(), trans_b=True, residual=resid),
+     lambda: ops.gemm_fp8(du8, q["1t"][0], 1 / sdu, q["1t"][1], a_format=1, residual=resid)),
+    ("fc1 fwd + e4m3 copy of h", 3072, lambda: ops.gemm(x, w1, bias=b1, aux=aux, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD),
+     lambda: (ops.gemm_fp8(x8, q["1"][0], 1 / sx, q["1"][1], bias=b1, aux=aux, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, q8_out=out8, q8_format=0, q8_scale=sh, q8_amax=amax)
+              if os.environ["MDT_GEMM_F8W"] == "1" else ops.gemm_fp8(x8, q["1"][0], 1 / sx, q["1"][1], bias=b1, aux=aux, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD))),
+    ("fc2 dgrad + e5m2 copy of du", 3072, lambda: ops.gemm(dy, w2t.t().contiguous(), trans_b=True, aux=saved, epilogue=ops.EPI_MULAUX, colsum=cs),
+     lambda: (ops.gemm_fp8(d8, q["2"][0], 1 / sd, q["2"][1], a_format=1, aux=saved, epilogue=ops.EPI_MULAUX, colsum=cs, q8_out=out8, q8_format=1, q8_scale=sdu, q8_amax=amax)
+              if os.environ["MDT_GEMM_F8W"] == "1" else ops.gemm_fp8(d8, q["2"][0], 1 / sd, q["2"][1], a_format=1, aux=saved, epilogue=ops.EPI_MULAUX, colsum=cs))),
+]
 for name, n, f_bf, f_8 in sites:
     fl = 2.0 * M * n * 768
     t_b = timeit(f_bf)
