@@ -117,6 +117,12 @@ int mdt_colsum(void* stream, int dtype, int64_t M, int64_t N, const void* X, int
 int mdt_layernorm_fwd(void* stream, int dtype, int64_t rows, int D, const void* x, int64_t ldx,
                       const void* gamma, const void* beta, float eps,
                       void* y, int64_t ldy, float* mean, float* rstd);
+/* mdt_layernorm_fwd (bf16 rows) whose output ALSO leaves as fp8 for the 8-bit GEMM that consumes it (fp8 operands, below):
+ * q8_out u8[rows, D] (rows of ld_q8 bytes) = saturate(q8_format, y * *q8_scale), *q8_amax = max(*q8_amax, max |y|) — bit for bit
+ * what mdt_fp8_quantize makes of y, without its pass over y.  q8_out NULL: plain mdt_layernorm_fwd. */
+int mdt_layernorm_fwd_q8(void* stream, int dtype, int64_t rows, int D, const void* x, int64_t ldx, const void* gamma,
+                         const void* beta, float eps, void* y, int64_t ldy, float* mean, float* rstd, void* q8_out,
+                         int64_t ld_q8, int q8_format, const float* q8_scale, float* q8_amax);
 /* dx = LN'(dy) (+ add[m,:] if add != NULL);  dgamma/dbeta fp32, atomically accumulated.
  * Optional fused tail for the layer that FEEDS this LayerNorm through a hidden dropout + residual:
  *   dxd (may be NULL) = dx * keep(drop_seed, m*D + n) / (1 - drop_p)   — gradient of the dense output,

@@ -53,6 +53,7 @@ _SIGS = {
     "mdt_dropout_mask": ([_vp, _i64, _f, C.c_uint64, _vp], _i),
     "mdt_colsum": ([_vp, _i, _i64, _i64, _vp, _i64, _vp, _vp], _i),
     "mdt_layernorm_fwd": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _vp, _f, _vp, _i64, _vp, _vp], _i),
+    "mdt_layernorm_fwd_q8": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _vp, _f, _vp, _i64, _vp, _vp, _vp, _i64, _i, _vp, _vp], _i),
     "mdt_layernorm_bwd": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp,
                            _vp, _i64, _f, C.c_uint64, _vp], _i),
     "mdt_attention_fwd": ([_vp, C.POINTER(AttnFwdArgs)], _i),

@@ -25,16 +25,27 @@ template <> struct Vec<bf16_t> {
 // A wave walks rows wid, wid + nwaves, ...; the next row is requested before the current one is reduced, so a wave keeps
 // two rows (and an 8-workgroup CU 64 of them, ~100 KiB) in flight — with one row per wave and no look-ahead the kernel
 // moved 4.1 TB/s, bounded by bytes in flight over the ~2 us of an HBM round trip.
-template <typename T, int NV>
+// Q8 (bf16 only): y ALSO leaves as fp8 (1: e4m3, 2: e5m2) for the 8-bit GEMM that consumes it — q8 = saturate(bf16(y) * *q8_scale),
+// *q8_amax = max(*q8_amax, max |bf16(y)|), the bytes and the maximum mdt_fp8_quantize would make of y (fp8.hip), without its pass
+template <typename T, int NV, int Q8 = 0>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int D, const T* __restrict__ x, int64_t ldx,
                                                             const T* __restrict__ gamma, const T* __restrict__ beta,
                                                             float eps, T* __restrict__ y, int64_t ldy,
-                                                            float* __restrict__ mean, float* __restrict__ rstd) {
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            uint8_t* __restrict__ q8 = nullptr, int64_t ldq = 0,
+                                                            const float* __restrict__ q8_scale = nullptr, float* __restrict__ q8_amax = nullptr) {
   constexpr int VN = Vec<T>::N;
   const int lane = threadIdx.x & 63;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  float qmax = 0.f;
+  const float qs = Q8 != 0 ? *q8_scale : 1.0f;
+  __shared__ float s_qmax[4];
+  if constexpr (Q8 != 0) {
+    if (threadIdx.x < 4) s_qmax[threadIdx.x] = 0.f;
+    __syncthreads();
+  }
+  if (row < rows) {
   Vec<T> gv[NV], bv[NV], xv[NV], xn[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -84,12 +95,41 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int D,
 #pragma unroll
         for (int j = 0; j < VN; ++j) o.set(j, (xv[i].get(j) - mu) * rs * gv[i].get(j) + bv[i].get(j));
         *(Vec<T>*)(yr + c) = o;
+        if constexpr (Q8 != 0 && VN == 8) {
+          constexpr float FMAX = Q8 == 1 ? 448.0f : 57344.0f;
+          float qv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float r = o.get(j);                 // the ROUNDED output
+            qmax = fmaxf(qmax, fabsf(r));
+            qv[j] = __builtin_amdgcn_fmed3f(r * qs, -FMAX, FMAX);
+          }
+          int w0 = 0, w1 = 0;
+          if constexpr (Q8 == 1) {
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[0], qv[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[2], qv[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[4], qv[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[6], qv[7], w1, true);
+          } else {
+            w0 = __builtin_amdgcn_cvt_pk_bf8_f32(qv[0], qv[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(qv[2], qv[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_bf8_f32(qv[4], qv[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(qv[6], qv[7], w1, true);
+          }
+          *(int2*)(q8 + row * ldq + c) = make_int2(w0, w1);
+        }
       }
     }
     if (next >= rows) break;
     row = next;
 #pragma unroll
     for (int i = 0; i < NV; ++i) xv[i] = xn[i];
+  }
+  }
+  if constexpr (Q8 != 0) {          // one atomic per workgroup (non-negative floats order like their bit patterns)
+    qmax = wave_max(qmax);
+    if (lane == 0) s_qmax[threadIdx.x >> 6] = qmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float m = fmaxf(fmaxf(s_qmax[0], s_qmax[1]), fmaxf(s_qmax[2], s_qmax[3]));
+      if (m > 0.f) atomicMax((int*)q8_amax, __float_as_int(m));
+    }
   }
 }
 
@@ -222,15 +262,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
 
 template <typename T>
 static int ln_fwd_dispatch(hipStream_t st, int64_t rows, int D, const void* x, int64_t ldx, const void* gamma,
-                           const void* beta, float eps, void* y, int64_t ldy, float* mean, float* rstd) {
+                           const void* beta, float eps, void* y, int64_t ldy, float* mean, float* rstd, void* q8 = nullptr,
+                           int64_t ldq = 0, int q8_fmt = 0, const float* q8_scale = nullptr, float* q8_amax = nullptr) {
   constexpr int VN = Vec<T>::N;
   const int nv = (D + 64 * VN - 1) / (64 * VN);
   // 8 resident workgroups per CU (32 waves, two rows in flight each); short inputs get one row per wave
   const int64_t wgs = (rows + 3) / 4;
   const unsigned grid = (unsigned)(wgs < 2048 ? wgs : 2048);
 #define LN_FWD(NV_)                                                                                          \
-  hipLaunchKernelGGL((layernorm_fwd_kernel<T, NV_>), grid, 256, 0, st, rows, D, (const T*)x, ldx,          \
-                     (const T*)gamma, (const T*)beta, eps, (T*)y, ldy, mean, rstd)
+  if (q8 && q8_fmt == 0)                                                                                     \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<T, NV_, 1>), grid, 256, 0, st, rows, D, (const T*)x, ldx, (const T*)gamma, (const T*)beta, \
+                       eps, (T*)y, ldy, mean, rstd, (uint8_t*)q8, ldq, q8_scale, q8_amax);                   \
+  else if (q8)                                                                                               \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<T, NV_, 2>), grid, 256, 0, st, rows, D, (const T*)x, ldx, (const T*)gamma, (const T*)beta, \
+                       eps, (T*)y, ldy, mean, rstd, (uint8_t*)q8, ldq, q8_scale, q8_amax);                   \
+  else                                                                                                       \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<T, NV_>), grid, 256, 0, st, rows, D, (const T*)x, ldx,        \
+                       (const T*)gamma, (const T*)beta, eps, (T*)y, ldy, mean, rstd, (uint8_t*)nullptr, (int64_t)0, (const float*)nullptr, (float*)nullptr)
   switch (nv) {
     case 1: LN_FWD(1); break;
     case 2: LN_FWD(2); break;
@@ -305,6 +353,21 @@ extern "C" int mdt_layernorm_fwd(void* stream, int dtype, int64_t rows, int D, c
   hipStream_t st = (hipStream_t)stream;
   return dtype == MDT_F32 ? ln_fwd_dispatch<float>(st, rows, D, x, ldx, gamma, beta, eps, y, ldy, mean, rstd)
                           : ln_fwd_dispatch<bf16_t>(st, rows, D, x, ldx, gamma, beta, eps, y, ldy, mean, rstd);
+}
+
+extern "C" int mdt_layernorm_fwd_q8(void* stream, int dtype, int64_t rows, int D, const void* x, int64_t ldx,
+                                    const void* gamma, const void* beta, float eps, void* y, int64_t ldy, float* mean,
+                                    float* rstd, void* q8_out, int64_t ld_q8, int q8_format, const float* q8_scale, float* q8_amax) {
+  if (!q8_out) return mdt_layernorm_fwd(stream, dtype, rows, D, x, ldx, gamma, beta, eps, y, ldy, mean, rstd);
+  if (rows == 0) return MDT_OK;
+  MDT_CHECK_ARG(x && y && gamma && beta, "layernorm_fwd_q8: null pointer");
+  MDT_CHECK_ARG(dtype == MDT_BF16, "layernorm_fwd_q8: the fp8 copy exists for bf16 rows only (dtype %d)", dtype);
+  MDT_CHECK_ARG(q8_format == 0 || q8_format == 1, "layernorm_fwd_q8: q8_format %d (0 = e4m3, 1 = e5m2)", q8_format);
+  MDT_CHECK_ARG(q8_scale && q8_amax && ld_q8 >= D && ld_q8 % 8 == 0 && ((uintptr_t)q8_out & 7) == 0,
+                "layernorm_fwd_q8: the fp8 copy needs its scale, its maximum slot and 8-byte aligned rows of at least D bytes");
+  if (int e = ln_check(dtype, D, ldx, ldy, x, y)) return e;
+  MDT_CHECK_ARG((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "layernorm_fwd_q8: gamma/beta must be 16-byte aligned");
+  return ln_fwd_dispatch<bf16_t>((hipStream_t)stream, rows, D, x, ldx, gamma, beta, eps, y, ldy, mean, rstd, q8_out, ld_q8, q8_format, q8_scale, q8_amax);
 }
 
 extern "C" int mdt_layernorm_bwd(void* stream, int dtype, int64_t rows, int D, const void* dy, int64_t lddy,

@@ -386,6 +386,14 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         """the 8-bit kernel where it pays (fp8.py) and the shape allows, else None"""
         return None if f8 is None else f8.linear(x_, w_, (tag, id(w_)), **kw_)
 
+    def ln8(x_, lw, lb, w_, tag):
+        """LayerNorm whose output feeds the 8-bit GEMM (tag, w_): the fp8 copy leaves the LayerNorm kernel itself when that site
+        has a scale (fp8.py producer_slot).  → (y, mean, rstd, (y8, inv scale) or None)"""
+        slot = None if (f8 is None or x_.dtype != torch.bfloat16) else f8.producer_slot(x_.shape[0], w_, (tag, id(w_)))
+        if slot is None:
+            return (*ops.layernorm_fwd(x_, lw.data, lb.data, eps), None)
+        return (*ops.layernorm_fwd(x_, lw.data, lb.data, eps, q8=slot[:4]), (slot[0], slot[4]))
+
     if not pre_ln:
         qkv = lin8(xd, P.qkv_w, "qkv", bias=P.qkv_b.data)
         if qkv is None:
@@ -393,9 +401,9 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
         ctx_full, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw, **akw)
         ctx, xk = gather(ctx_full), gather(xd)
         t = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xk, drop_p=p_hidden, drop_seed=s_o)
-        a, m1, r1 = ops.layernorm_fwd(t, P.ln1_w.data, P.ln1_b.data, eps)
+        a, m1, r1, a8 = ln8(t, P.ln1_w, P.ln1_b, P.fc1_w, "fc1")
         u = torch.empty(a.shape[0], P.fc1_w.shape[0], dtype=a.dtype, device=a.device)
-        h, h8 = lin8(a, P.fc1_w, "fc1", bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act,
+        h, h8 = lin8(a, P.fc1_w, "fc1", x8=a8, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act,
                      q8_site=("fc2", id(P.fc2_w))) or (None, None)
         if h is None:
             h = ops.gemm(a, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act)
@@ -404,16 +412,16 @@ def transformer_block(tape: Tape, x: Var, P: BlockParams, spec: AttnSpec, *, pre
             y = ops.gemm(h, P.fc2_w.data, bias=P.fc2_b.data, residual=a, drop_p=p_hidden, drop_seed=s_f2)
         out, m2, r2 = ops.layernorm_fwd(y, P.ln2_w.data, P.ln2_b.data, eps)
     else:
-        n1, m1, r1 = ops.layernorm_fwd(xd, P.ln1_w.data, P.ln1_b.data, eps)
-        qkv = lin8(n1, P.qkv_w, "qkv", bias=P.qkv_b.data)
+        n1, m1, r1, n18 = ln8(xd, P.ln1_w, P.ln1_b, P.qkv_w, "qkv")
+        qkv = lin8(n1, P.qkv_w, "qkv", x8=n18, bias=P.qkv_b.data)
         if qkv is None:
             qkv = ops.gemm(n1, P.qkv_w.data, bias=P.qkv_b.data)
         ctx_full, lse = ops.attention_fwd(qkv, spec.nseq, spec.S, spec.H, **kw, **akw)
         ctx, xk = gather(ctx_full), gather(xd)
         hmid = ops.gemm(ctx, P.o_w.data, bias=P.o_b.data, residual=xk, drop_p=p_hidden, drop_seed=s_o)
-        n2, m2, r2 = ops.layernorm_fwd(hmid, P.ln2_w.data, P.ln2_b.data, eps)
+        n2, m2, r2, n28 = ln8(hmid, P.ln2_w, P.ln2_b, P.fc1_w, "fc1")
         u = torch.empty(n2.shape[0], P.fc1_w.shape[0], dtype=n2.dtype, device=n2.device)
-        f, f8q = lin8(n2, P.fc1_w, "fc1", bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act,
+        f, f8q = lin8(n2, P.fc1_w, "fc1", x8=n28, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act,
                       q8_site=("fc2", id(P.fc2_w))) or (None, None)
         if f is None:
             f = ops.gemm(n2, P.fc1_w.data, bias=P.fc1_b.data, aux=u, epilogue=ops.EPI_GELU | ops.EPI_AUX_GRAD, drop_p=p_act, drop_seed=s_act)

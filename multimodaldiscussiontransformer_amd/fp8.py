@@ -104,6 +104,20 @@ class Fp8State:
             self.inv[i] = (a * MARGIN) / ops.FP8_MAX[fmt]
         return new
 
+    def producer_slot(self, rows: int, w: torch.nn.Parameter, site, fmt=ops.FP8_E4M3, transposed_weight: bool = False):
+        """For the kernel that PRODUCES the operand of the 8-bit GEMM ``site`` (a LayerNorm in front of the QKV / fc1
+        projection): (u8[rows, K] buffer, format, scale view, amax view, inv-scale view) to write the fp8 copy and its maximum
+        into — or None when that GEMM will not take the 8-bit kernel, the site has no scale yet (first sight: the consumer
+        measures the tensor itself), or producers are told not to (MDT_FP8_FUSED_Q=0).  Hand ``(buffer, inv view)`` to
+        ``linear(..., x8=...)``."""
+        n_out = w.shape[1] if transposed_weight else w.shape[0]
+        k = w.shape[0] if transposed_weight else w.shape[1]
+        i = self.sites.get(site)
+        if i is None or not FUSED_Q or site[0] not in self.site_names or w.dtype != torch.bfloat16 or not self.eligible(rows, n_out, k):
+            return None
+        self.fused_outputs += 1
+        return torch.empty(rows, k, dtype=torch.uint8, device=self.device), fmt, self.scale[i:i + 1], self.amax[i:i + 1], self.inv[i:i + 1]
+
     def weight(self, w: torch.nn.Parameter, transposed: bool = False):
         """e4m3 copy of a weight ([N, K], or its transpose for dX = dY W), cached until the optimiser steps."""
         key = (id(w), transposed)

@@ -78,12 +78,21 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, row_weight=None)
     return out
 
 
-def layernorm_fwd(x, gamma, beta, eps, out=None):
+def layernorm_fwd(x, gamma, beta, eps, out=None, q8=None):
+    """→ (y, mean, rstd).  ``q8`` = (u8[rows, D] out, format, scale, amax): y also leaves as fp8 for the 8-bit GEMM that consumes
+    it (= fp8_quantize(y, format, scale, amax) without its pass)."""
     rows, D = x.shape
     if out is None:
         out = torch.empty_like(x)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    if q8 is not None:
+        q8_out, q8_format, q8_scale, q8_amax = q8
+        assert q8_out.dtype == torch.uint8 and q8_out.shape == (rows, D)
+        check(lib.mdt_layernorm_fwd_q8(stream(), dt(x), rows, D, ptr(x), _2d(x), ptr(gamma), ptr(beta), float(eps), ptr(out), _2d(out),
+                                       ptr(mean), ptr(rstd), ptr(q8_out), _2d(q8_out), int(q8_format), ptr(q8_scale), ptr(q8_amax)),
+              "mdt_layernorm_fwd_q8")
+        return out, mean, rstd
     check(lib.mdt_layernorm_fwd(stream(), dt(x), rows, D, ptr(x), _2d(x), ptr(gamma), ptr(beta), float(eps), ptr(out),
                                 _2d(out), ptr(mean), ptr(rstd)), "mdt_layernorm_fwd")
     return out, mean, rstd

@@ -170,6 +170,26 @@ def test_gemm_fp8_quantised_second_output_equals_a_quantisation_pass(ops, M):
         assert float(amax_a) == float(amax_b) == float(plain.float().abs().max())
 
 
+@pytest.mark.parametrize("rows,D", [(70001, 768), (5, 768), (4099, 1024)])
+@pytest.mark.parametrize("fmt,fmax", [(0, 448.0), (1, 57344.0)])
+def test_layernorm_quantised_second_output_equals_a_quantisation_pass(ops, rows, D, fmt, fmax):
+    """mdt_layernorm_fwd_q8: the LayerNorm in front of an 8-bit GEMM writes that GEMM's operand itself — same bytes and same
+    running maximum as mdt_fp8_quantize on its bf16 output, and the bf16 output / statistics unchanged."""
+    g = torch.Generator(device="cuda").manual_seed(41)
+    x = (torch.randn(rows, D, device="cuda", generator=g) * 3.0).bfloat16()
+    gamma = (1.0 + 0.3 * torch.randn(D, device="cuda", generator=g)).bfloat16()
+    beta = (0.2 * torch.randn(D, device="cuda", generator=g)).bfloat16()
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-12)
+    scale = (fmax / y.float().abs().max() * 2.5).reshape(1)               # saturates part of the tensor on purpose
+    amax_a, amax_b = torch.full((1,), 1e-3, device="cuda"), torch.full((1,), 1e-3, device="cuda")
+    y8 = torch.full((rows, D), 0x55, device="cuda", dtype=torch.uint8)
+    y2, mean2, rstd2 = ops.layernorm_fwd(x, gamma, beta, 1e-12, q8=(y8, fmt, scale, amax_a))
+    want8 = ops.fp8_quantize(y, fmt, scale=scale, amax=amax_b)
+    assert torch.equal(y2, y) and torch.equal(mean2, mean) and torch.equal(rstd2, rstd)
+    assert torch.equal(y8, want8), int((y8 != want8).sum())
+    assert float(amax_a) == float(amax_b) == float(y.float().abs().max())
+
+
 def test_unsupported_shapes_are_refused_not_miscomputed(ops):
     from multimodaldiscussiontransformer_amd._lib import MdtError
     one = torch.ones(1, device="cuda")
