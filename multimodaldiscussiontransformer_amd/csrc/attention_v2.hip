@@ -32,6 +32,52 @@ __device__ __forceinline__ void v2_stage(bf16_t* img, const bf16_t* g, int64_t g
   }
 }
 
+// The same staging in two halves: every 16-byte chunk a thread owns is REQUESTED before any is waited for.  The
+// loop above waits for each of its loads before the LDS write of the same iteration (the compiler keeps a runtime
+// trip count rolled), so a workgroup that stages two images in 2-4 iterations each pays 4-8 global latencies one
+// after the other before its first MFMA; with the chunks held in registers (NCH x 4 per image) it pays one.
+// The requests are unconditional — rows past S read row S - 1 again (S >= 1: the callers return on empty sequences)
+// and become zeros when they are put: a load under a lane mask leaves the compiler a merge with the zero value
+// that it resolves with a register copy behind s_waitcnt vmcnt(0), which is the serialisation this is here to remove.
+template <int HD, int NCH>
+__device__ __forceinline__ void v2_stage_req(bf16x8 (&v)[NCH], const bf16_t* g, int64_t g_ld, int S, int tid, int nthr) {
+  constexpr int CH = HD / 8;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int e = tid + j * nthr, r = e / CH, c = e - r * CH;
+    v[j] = *(const bf16x8*)(g + (r < S ? r : S - 1) * g_ld + c * 8);
+  }
+}
+// `spare`: 16 bytes of LDS that chunks past the image land in — with the write under a lane mask instead, the compiler
+// sinks the chunk's load into the masked block and waits for it there (one more latency)
+template <int HD, int NCH>
+__device__ __forceinline__ void v2_stage_put(bf16_t* img, const bf16x8 (&v)[NCH], int S, int rows_pad, int tid, int nthr, bf16_t* spare) {
+  constexpr int CH = HD / 8;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int e = tid + j * nthr, r = e / CH, c = e - r * CH;
+    bf16_t* dst = e < rows_pad * CH ? img + r * V2_LD + c * 8 : spare;
+    *(bf16x8*)dst = r < S ? v[j] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+}
+// key-only bias, its mask bytes requested without a lane mask (same reason); key_only_bias_of turns them into 0 / -inf
+struct KeyBytes { uint8_t km, kp; };
+__device__ __forceinline__ KeyBytes key_only_bias_req(const BiasCtx& b, int key, const void* readable) {
+  KeyBytes k{1, 0};
+  if (b.key_mask || b.key_pad) {      // uniform; without masks (ragged rows, images) nothing is read
+    const int64_t at = (int64_t)b.seq * b.S + (key < b.S ? key : b.S - 1);
+    // one of the two absent: it reads a byte of `readable` (any mapped address) instead of branching around its load
+    const uint8_t* pm = b.key_mask ? b.key_mask + at : (const uint8_t*)readable;
+    const uint8_t* pp = b.key_pad ? b.key_pad + at : (const uint8_t*)readable;
+    const uint8_t m = *pm, q = *pp;
+    k = KeyBytes{(uint8_t)(b.key_mask ? m : 1), (uint8_t)(b.key_pad ? q : 0)};
+  }
+  return k;
+}
+__device__ __forceinline__ float key_only_bias_of(const BiasCtx& b, int key, KeyBytes k) {
+  return (key < b.S && k.km && !k.kp) ? 0.f : -INFINITY;
+}
+
 // A / B fragment with k along the contiguous axis: element(rc, k) = p[rc*ld + k]
 __device__ __forceinline__ bf16x8 v2_frag_lds(const bf16_t* img, int rc0, int k0, int lane) {
   const bf16_t* a = img + (rc0 + (lane & 15)) * V2_LD + k0 + 8 * (lane >> 4);
@@ -65,6 +111,38 @@ __device__ __forceinline__ float col_sum(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
+// Output rows leave as 32 contiguous bytes per lane.  An accumulator set x[d'][r] of a 16-row x 64-column result holds,
+// in lane (g, c), columns 16 d' + 4 g + r of row c: four 8-byte pieces 32 bytes apart, and a wave store of one piece
+// writes 32-byte fragments of 16 different rows (sixteen quarter-filled 128-byte lines per instruction; the stores of the
+// one-pass backward ran at 2.8-3.5 TB/s for it).  A 4 x 4 exchange among the four 16-lane rows of the wave — piece d' of
+// row g trades places with piece g of row d': v_permlane32_swap on the pairs (0, 2), (1, 3), then v_permlane16_swap on
+// (0, 1), (2, 3) — leaves lane (g, c) with columns 16 g ... 16 g + 15 of row c in order, which go out as two 16-byte
+// stores (the same bytes in a quarter of the fragments: measured 4.6 TB/s).  All 64 lanes must be active.
+// Inline asm with s_nop 1 for the reason given in gemm_epilogue.hpp (builtin folded by hipcc; VALU write -> swap hazard).
+struct Row32 { bf16x8 a, b; };
+__device__ __forceinline__ Row32 rows4_exchange(const f32x4 (&x)[4], float scale) {
+  uint32_t lo[4], hi[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const bf16x4 v = bf16x4{(bf16_t)(x[d][0] * scale), (bf16_t)(x[d][1] * scale), (bf16_t)(x[d][2] * scale), (bf16_t)(x[d][3] * scale)};
+    const uint2 u = __builtin_bit_cast(uint2, v);
+    lo[d] = u.x;
+    hi[d] = u.y;
+  }
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo[0]), "+v"(lo[2]));
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo[1]), "+v"(lo[3]));
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(hi[0]), "+v"(hi[2]));
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(hi[1]), "+v"(hi[3]));
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo[0]), "+v"(lo[1]));
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo[2]), "+v"(lo[3]));
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(hi[0]), "+v"(hi[1]));
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(hi[2]), "+v"(hi[3]));
+  Row32 r;
+  r.a = __builtin_bit_cast(bf16x8, uint4{lo[0], hi[0], lo[1], hi[1]});
+  r.b = __builtin_bit_cast(bf16x8, uint4{lo[2], hi[2], lo[3], hi[3]});
+  return r;
+}
+
 // ---------------------------------------------------------------------------- forward
 // Softmax in the exp2 domain (scores and key bias pre-multiplied by log2 e: v_exp_f32 is exp2), masked keys
 // carry -inf so no element needs a compare; the probabilities stay UNNORMALISED (e <= 1) through P.V and the
@@ -81,7 +159,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_v2_kernel(AttnParams P) {
   const int SL = a.S, D = a.H * HD;                      // SL: lse / dropout-counter geometry
   const int S = a.seq_offsets ? a.seq_offsets[seq + 1] - a.seq_offsets[seq] : a.S;   // this sequence's length
   const int64_t row0 = a.seq_offsets ? (int64_t)a.seq_offsets[seq] : (int64_t)seq * a.seq_stride;
-  if (S > NT * 16) return;      // longer than this launch's bound (s_cap): never index past the images
+  if (S > NT * 16 || S <= 0) return;      // longer than this launch's bound (s_cap): never index past the images; empty: nothing to write
   const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * a.ld_qkv + h * HD;
   const int64_t tld = a.pos_stride * a.ld_qkv;
   bf16_t* imgK = (bf16_t*)smem;
@@ -107,9 +185,21 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_v2_kernel(AttnParams P) {
       for (int ks = 0; ks < HD / 32; ++ks) fq_all[k][ks] = v2_frag_glb(qkv, tld, S, qt_k * 16, ks * 32, lane);
     }
   }
-  v2_stage<HD>(imgK, qkv + D, tld, S, S_PAD, tid, NW * 64);
-  v2_stage<HD>(imgV, qkv + 2 * D, tld, S, S_PAD, tid, NW * 64);
-  for (int i = tid; i < S_PAD; i += NW * 64) s_kb[i] = key_only_bias<bf16_t>(bc, i);
+  // ... and so are all K / V chunks and mask bytes of this thread (v2_stage_req): one global latency before the barrier
+  {
+    constexpr int NCH = (S_PAD * (HD / 8) + NW * 64 - 1) / (NW * 64), NKB = (S_PAD + NW * 64 - 1) / (NW * 64);
+    bf16x8 ck[NCH], cv[NCH];
+    KeyBytes kbv[NKB];
+    v2_stage_req<HD, NCH>(ck, qkv + D, tld, S, tid, NW * 64);
+    v2_stage_req<HD, NCH>(cv, qkv + 2 * D, tld, S, tid, NW * 64);
+#pragma unroll
+    for (int j = 0; j < NKB; ++j) kbv[j] = key_only_bias_req(bc, tid + j * NW * 64, qkv);
+    v2_stage_put<HD, NCH>(imgK, ck, S, S_PAD, tid, NW * 64, (bf16_t*)(s_kb + S_PAD));
+    v2_stage_put<HD, NCH>(imgV, cv, S, S_PAD, tid, NW * 64, (bf16_t*)(s_kb + S_PAD));
+#pragma unroll
+    for (int j = 0; j < NKB; ++j)
+      if (tid + j * NW * 64 < S_PAD) s_kb[tid + j * NW * 64] = key_only_bias_of(bc, tid + j * NW * 64, kbv[j]);
+  }
   __syncthreads();
   const int drop_bh = seq * a.H + h;   // counters: attention_common.hpp
   const float scale2 = a.scale * LOG2E;
@@ -191,11 +281,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_v2_kernel(AttnParams P) {
       for (int d = 0; d < ND; ++d) o[d] = mfma_bf16(v2_frag_tr(imgV, 2 * pi, d * 16, lane), fp, o[d]);
       __builtin_amdgcn_sched_barrier(0);
     }
+    static_assert(ND == 4, "rows4_exchange: 64-column rows");
+    const Row32 ov = rows4_exchange(o, inv);      // inv is per query = per lane column c: the same in the four lanes that trade
     if (q < S) {
-      bf16_t* orow = (bf16_t*)a.out + (row0 + (int64_t)q * a.pos_stride) * a.ld_out + h * HD + 4 * g;
-#pragma unroll
-      for (int d = 0; d < ND; ++d)
-        *(bf16x4*)(orow + d * 16) = bf16x4{(bf16_t)(o[d][0] * inv), (bf16_t)(o[d][1] * inv), (bf16_t)(o[d][2] * inv), (bf16_t)(o[d][3] * inv)};
+      bf16_t* orow = (bf16_t*)a.out + (row0 + (int64_t)q * a.pos_stride) * a.ld_out + h * HD + 16 * g;
+      *(bf16x8*)orow = ov.a;
+      *(bf16x8*)(orow + 8) = ov.b;
     }
   }
 }
@@ -754,59 +845,76 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
   BiasCtx bc{seq, h, S, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
   const int n_t = (S + 15) >> 4;
   const int rows_live = ((n_t + 1) >> 1) * 32;         // this sequence's rows, in pairs of tiles (zero rows past S)
-  if (rows_live > rows_img) return;                    // longer than this launch's bound (s_cap)
-  v2_stage<HD>(img0, qkv, tld, S, rows_live, tid, nthr);    // Q
+  if (rows_live > rows_img || S <= 0) return;          // longer than this launch's bound (s_cap); empty: nothing to write
   const float ik = DROP ? P.drop.inv_keep : 1.0f, rik = 1.0f / ik;
-  // dO is staged by the same (row, 16-byte chunk) walk that forms delta = rowsum(dO * O): the 8 lanes of a row hold
-  // its 8 chunks, three shuffles finish the row (rows_live * 8 is a multiple of 64: whole waves, no divergence)
-  {
-    const int q_rows = (a.q_limit > 0 && ((a.q_limit + 15) & ~15) < S) ? ((a.q_limit + 15) & ~15) : S;   // rows the forward computed
-    for (int e = tid; e < rows_live * (HD / 8); e += nthr) {
-      const int r = e / (HD / 8), c8 = e - r * (HD / 8);
-      bf16x8 gv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      float de = 0.f;
-      if (r < S) {
-        gv = *(const bf16x8*)(dout + r * dld + c8 * 8);
-        if (r < q_rows) {
-          const bf16x8 o = *(const bf16x8*)(outp + r * old_ + c8 * 8);
+  const int g = lane >> 4, c = lane & 15;
+  // Everything this item reads from global memory is REQUESTED here, before anything is waited for: the wave's K / V
+  // fragments (a wave owns at most one key tile: the host launches >= n_t waves), then per thread at most two 16-byte
+  // chunks each of Q, dO and O (the host checks rows_img * 8 <= 2 * nthr), its lse value and mask bytes.  The rolled
+  // staging loops this replaces waited for every load inside its own iteration — nine global latencies one after the
+  // other per (sequence, head), which was most of the 22 us such an item lived (5-6 us of it arithmetic).
+  const int kt = wave, key0 = kt * 16;
+  bf16x8 fk[HD / 32], fv[HD / 32];
+  if (kt < n_t) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) de += (float)o[k] * (float)gv[k];
-        }
-      }
-      *(bf16x8*)(img1 + r * V2_LD + c8 * 8) = gv;
-      de += __shfl_xor(de, 1, 64);
-      de += __shfl_xor(de, 2, 64);
-      de += __shfl_xor(de, 4, 64);
-      if (c8 == 0) s_delta[r] = de * rik;
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      fk[ks] = v2_frag_glb(qkv + D, tld, S, key0, ks * 32, lane);
+      fv[ks] = v2_frag_glb(qkv + 2 * D, tld, S, key0, ks * 32, lane);
     }
-    for (int i = tid; i < rows_live; i += nthr) {
-      s_kb[i] = key_only_bias<bf16_t>(bc, i);
-      const float l = i < q_rows ? a.lse[((int64_t)seq * a.H + h) * SL + i] : -INFINITY;
-      s_lse[i] = (l == -INFINITY) ? INFINITY : l * LOG2E;
+  }
+  {
+    static_assert(HD == 64, "delta reduction and staging assume 8 chunks per row");
+    const int q_rows = (a.q_limit > 0 && ((a.q_limit + 15) & ~15) < S) ? ((a.q_limit + 15) & ~15) : S;   // rows the forward computed
+    bf16x8 cq[2], cg[2], co[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {      // no lane masks around the requests: see v2_stage_req
+      const int e = tid + j * nthr, r = e >> 3, c8 = e & 7;
+      const int rc = r < S ? r : S - 1, ro = r < q_rows ? r : q_rows - 1;
+      cq[j] = *(const bf16x8*)(qkv + rc * tld + c8 * 8);
+      cg[j] = *(const bf16x8*)(dout + rc * dld + c8 * 8);
+      co[j] = *(const bf16x8*)(outp + ro * old_ + c8 * 8);
+    }
+    const int ti = tid < rows_live ? tid : 0;
+    const float lv = a.lse[((int64_t)seq * a.H + h) * SL + (ti < q_rows ? ti : q_rows - 1)];
+    const KeyBytes kbv = key_only_bias_req(bc, ti, qkv);
+    // Q -> img0; dO -> img1 by the same (row, chunk) walk that forms delta = rowsum(dO * O): the 8 lanes of a row hold
+    // its 8 chunks, three shuffles finish the row (rows_live * 8 is a multiple of 64: whole waves, no divergence)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + j * nthr, r = e >> 3, c8 = e & 7;
+      if (e < rows_live * 8) {
+        const bf16x8 z = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        const bf16x8 gv = r < S ? cg[j] : z;
+        *(bf16x8*)(img0 + r * V2_LD + c8 * 8) = r < S ? cq[j] : z;
+        *(bf16x8*)(img1 + r * V2_LD + c8 * 8) = gv;
+        float de = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) de += (float)co[j][k] * (float)gv[k];
+        de += __shfl_xor(de, 1, 64);
+        de += __shfl_xor(de, 2, 64);
+        de += __shfl_xor(de, 4, 64);
+        if (c8 == 0) s_delta[r] = r < q_rows ? de * rik : 0.f;
+      }
+    }
+    if (tid < rows_live) {
+      s_kb[tid] = key_only_bias_of(bc, tid, kbv);
+      s_lse[tid] = (tid >= q_rows || lv == -INFINITY) ? INFINITY : lv * LOG2E;
     }
   }
   __syncthreads();
   const int drop_bh = seq * a.H + h;
   const uint32_t s2h = (uint32_t)((SL + 1) >> 1);
   const float scale2 = a.scale * LOG2E;
-  const int g = lane >> 4, c = lane & 15;
   const int n_tq = (a.q_limit > 0 && ((a.q_limit + 15) >> 4) < n_t) ? (a.q_limit + 15) >> 4 : n_t;
   const int n_pair_q = (n_tq + 1) >> 1, n_pair_k = (n_t + 1) >> 1;
 
   // ------------------------------------------------------------------ phase 1 (keys on lanes)
   const int odd = c & 1;
   const uint32_t base_rp = (uint32_t)(drop_bh * SL) * s2h;
-  for (int kt = wave; kt < n_t; kt += nw) {
-    const int key0 = kt * 16;
+  if (kt < n_t) {
     const int key = key0 + c;
     const bool kok = key < S;
     const float kb = s_kb[key];
-    bf16x8 fk[HD / 32], fv[HD / 32];
-#pragma unroll
-    for (int ks = 0; ks < HD / 32; ++ks) {
-      fk[ks] = v2_frag_glb(qkv + D, tld, S, key0, ks * 32, lane);
-      fv[ks] = v2_frag_glb(qkv + 2 * D, tld, S, key0, ks * 32, lane);
-    }
     const uint32_t kh = base_rp + (uint32_t)(key >> 1);
     bf16_t* ds_row = dsT + (key0 + c) * ldq + 4 * g;
     f32x4 dv[ND], dk[ND];
@@ -861,33 +969,25 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    static_assert(ND == 4, "rows4_exchange: 64-column rows");
+    const Row32 kv = rows4_exchange(dk, a.scale * ik), vv = rows4_exchange(dv, ik);
     if (kok) {
-      const float os = a.scale * ik;
-      bf16_t* krow = dqkv + (int64_t)key * gld + D + 4 * g;
-      bf16_t* vrow = dqkv + (int64_t)key * gld + 2 * D + 4 * g;
-#pragma unroll
-      for (int d = 0; d < ND; ++d) {
-        *(bf16x4*)(krow + d * 16) = bf16x4{(bf16_t)(dk[d][0] * os), (bf16_t)(dk[d][1] * os), (bf16_t)(dk[d][2] * os), (bf16_t)(dk[d][3] * os)};
-        *(bf16x4*)(vrow + d * 16) = bf16x4{(bf16_t)(dv[d][0] * ik), (bf16_t)(dv[d][1] * ik), (bf16_t)(dv[d][2] * ik), (bf16_t)(dv[d][3] * ik)};
-      }
+      bf16_t* krow = dqkv + (int64_t)key * gld + D + 16 * g;
+      bf16_t* vrow = dqkv + (int64_t)key * gld + 2 * D + 16 * g;
+      *(bf16x8*)krow = kv.a;
+      *(bf16x8*)(krow + 8) = kv.b;
+      *(bf16x8*)vrow = vv.a;
+      *(bf16x8*)(vrow + 8) = vv.b;
     }
   }
-  // K goes where Q was.  Its rows are requested BEFORE the barrier (at most two 16-byte chunks per thread at every
-  // workgroup size the host uses), so a wave that finishes its key tiles early — or owns none — spends the wait for the
-  // others on this latency instead of after it.
-  static_assert(HD == 64, "delta reduction and K restaging assume 8 chunks per row");
-  bf16x8 kpre[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int e = tid + j * nthr, r = e >> 3, c8 = e & 7;
-    kpre[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    if (e < rows_live * 8 && r < S) kpre[j] = *(const bf16x8*)(qkv + D + r * tld + c8 * 8);
-  }
+  // K goes where Q was — from the registers that already hold it: the K fragments of the waves ARE the rows of K (lane
+  // (g, c) of the owner of key tile kt holds chunks g and 4 + g of row 16 kt + c), so K is read from memory once per
+  // item, not twice, and no load stands between the two phases.  Rows past S inside a tile hold a copy of the last row
+  // (v2_frag_glb clamps) and meet dS^T rows that are exact zeros; the odd pair partner past n_t keeps Q's zero rows.
   __syncthreads();   // every dS^T tile is in LDS; the Q / dO images are free
+  if (kt < n_t) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int e = tid + j * nthr, r = e >> 3, c8 = e & 7;
-    if (e < rows_live * 8) *(bf16x8*)(img0 + r * V2_LD + c8 * 8) = kpre[j];
+    for (int ks = 0; ks < HD / 32; ++ks) *(bf16x8*)(img0 + (key0 + c) * V2_LD + ks * 32 + 8 * g) = fk[ks];
   }
   __syncthreads();
   // ------------------------------------------------------------------ phase 2 (queries on lanes): dQ^T = K^T dS^T
@@ -901,12 +1001,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
       for (int d = 0; d < ND; ++d) dq[d] = mfma_bf16(v2_frag_tr(img0, 2 * pk, d * 16, lane), fs, dq[d]);
     }
+    const Row32 qv = rows4_exchange(dq, a.scale * ik);
     if (q < S) {
-      const float os = a.scale * ik;
-      bf16_t* orow = dqkv + (int64_t)q * gld + 4 * g;
-#pragma unroll
-      for (int d = 0; d < ND; ++d)
-        *(bf16x4*)(orow + d * 16) = bf16x4{(bf16_t)(dq[d][0] * os), (bf16_t)(dq[d][1] * os), (bf16_t)(dq[d][2] * os), (bf16_t)(dq[d][3] * os)};
+      bf16_t* orow = dqkv + (int64_t)q * gld + 16 * g;
+      *(bf16x8*)orow = qv.a;
+      *(bf16x8*)(orow + 8) = qv.b;
     }
   }
 }
@@ -955,7 +1054,7 @@ static int launch_v3(hipStream_t st, const AttnParams& p) {
       }
       const int n_t = (cap + 15) / 16;
       const int waves = n_t <= 4 ? 4 : n_t <= 8 ? 8 : 16;
-      if (rows_img * 8 > 2 * waves * 64) {      // the kernel restages K with at most two 16-byte chunks per thread
+      if (rows_img * 8 > 2 * waves * 64 || n_t > waves) {      // two 16-byte chunks per thread and image, one key tile per wave
         set_error("attention_bwd_v4: %d image rows for %d waves", rows_img, waves);
         return MDT_ERR_UNSUPPORTED;
       }
@@ -989,7 +1088,7 @@ template <int NT, bool STRUCT, bool DROP, bool BWD>
 static int launch_v2(hipStream_t st, const AttnParams& p) {
   constexpr int S_PAD = ((NT + 1) / 2) * 32;
   const int nhist = (STRUCT && BWD) ? ((p.f.num_spatial + 1 + 3) & ~3) : 0;
-  const size_t lds = (size_t)2 * S_PAD * V2_LD * 2 + (size_t)(BWD ? 3 : 1) * S_PAD * 4 + (size_t)nhist * 4;
+  const size_t lds = (size_t)2 * S_PAD * V2_LD * 2 + (size_t)(BWD ? 3 : 1) * S_PAD * 4 + (size_t)nhist * 4 + (BWD ? 0 : 16);   // forward: + the staging's spare chunk
   if constexpr (BWD && NT > 7) {
     // the whole-row backward runs out of registers past 112 keys; attention.hip routes those to the chunked v3
     set_error("attention_v2: backward supports S <= 112 (got %d)", p.f.S);
