@@ -1010,6 +1010,321 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
   }
 }
 
+// ---------------------------------------------------------------------------- one-pass backward, persistent (v5)
+// The one-pass kernel for LONG rows (ViT: 197 tokens, 13 tiles).  There its images fill the LDS of a CU — one workgroup per CU
+// — and a (sequence, head) item runs request -> stage -> phase 1 -> K -> phase 2 -> stores with nothing beside it: measured
+// per launch (profiles/round3_experiments/attn_prologue_and_store_exchange.log) 140 us of reads at 5.5 TB/s + 290 us of
+// arithmetic + 100 us of stores = the 530 us it took; the two halves never overlap.  This form keeps the LDS layout and the
+// arithmetic of v4 and changes who waits for whom:
+//   * 8 waves of up to 256 registers instead of 16 of 128; a workgroup walks items blockIdx.x, + gridDim.x, ... and requests
+//     the NEXT item's Q / dO / O chunks, lse, mask bytes and K / V fragments (into the fragment registers, 82 VGPRs in all)
+//     as soon as phase 1 has written K to LDS: they arrive under phase 2 and the barriers, and no workgroup launch, kernel
+//     argument fetch or store drain stands between two items;
+//   * a wave owns key tiles w and w + 8 and runs both through ONE query-pair loop: the Q / dO fragments (row-major for
+//     S, dP; transposed for dV, dK), lse and delta vectors are read from LDS once for the two tiles — half the LDS read
+//     traffic per MFMA of v4, which together with the VALU stream is what bounds phase 1.
+// Operand values, summation orders and dropout decisions are those of v4: the outputs are bit-identical to it.
+// Measured (profiles/round3_experiments/attn_v5_persistent.log, 512 x 197 x 12 heads): 543 -> 526 us with dropout 0.3, 467 ->
+// 405 us without.  Where its time goes (phases switched off one by one): phase 1 310 us (195 without dropout: the two waves
+// of a SIMD issue its VALU stream at ~80 % of the pipe — the counter RNG is 37 % of it), phase 2 31, staging / barriers / K
+// 67, and ~105 us of the next item's requests still exposed: they are issued after phase 1, because their 82 registers on top
+// of phase 1's 233 do not fit, and phase 2 is too short to cover them.
+template <int HD, bool DROP, int NU>
+__device__ __forceinline__ void v5_phase1(const AttnParams& P, const bf16_t* img0, const bf16_t* img1, const float* s_kb, const float* s_lse,
+                                          const float* s_delta, bf16_t* dsT, int ldq, const bf16x8 (&wk)[2][HD / 32], const bf16x8 (&wv)[2][HD / 32],
+                                          int wave, int lane, int S, int SL, int drop_bh, int n_tq, bf16_t* dqkv, int64_t gld, int D, float ik) {
+  constexpr int ND = HD / 16;
+  const mdt_attn_fwd_args& a = P.f;
+  const int g = lane >> 4, c = lane & 15, odd = c & 1;
+  const uint32_t s2h = (uint32_t)((SL + 1) >> 1);
+  const float scale2 = a.scale * LOG2E;
+  const uint32_t base_rp = (uint32_t)(drop_bh * SL) * s2h;
+  const int n_pair_q = (n_tq + 1) >> 1;
+  int key[NU];
+  float kb[NU];
+  uint32_t kh[NU];
+  bf16_t* ds_row[NU];
+  f32x4 dv[NU][ND], dk[NU][ND];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    key[u] = (wave + 8 * u) * 16 + c;
+    kb[u] = s_kb[key[u]];
+    kh[u] = base_rp + (uint32_t)(key[u] >> 1);
+    ds_row[u] = dsT + key[u] * ldq + 4 * g;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) { dv[u][d] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[u][d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+  for (int pr = 0; pr < n_pair_q; ++pr) {
+    const int t0 = 2 * pr;
+    f32x4 sc[NU][2], dp[NU][2];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { sc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[u][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < HD / 32; ++ks) {
+        const bf16x8 aq = v2_frag_lds(img0, (t0 + t) * 16, ks * 32, lane), ao = v2_frag_lds(img1, (t0 + t) * 16, ks * 32, lane);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          sc[u][t] = mfma_bf16(aq, wk[u][ks], sc[u][t]);   // S[q][key]
+          dp[u][t] = mfma_bf16(ao, wv[u][ks], dp[u][t]);   // dP[q][key]
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 fp[NU], fs[NU];
+    {
+      f32x4 l2v[2], dlv[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int qb = (t0 + t) * 16 + 4 * g;
+        l2v[t] = *(const f32x4*)(s_lse + qb);
+        dlv[t] = *(const f32x4*)(s_delta + qb);
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int qb = (t0 + t) * 16 + 4 * g;
+          bool keep[4] = {true, true, true, true};
+          if constexpr (DROP) {
+            const uint32_t ra = kh[u] + (uint32_t)(qb + 2 * odd) * s2h;
+            const uint32_t wa = drop_mix(ra ^ P.drop.key), wb = drop_mix((ra + s2h) ^ P.drop.key);
+            const uint32_t pa = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wa, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+            const uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wb, 0xB1, 0xF, 0xF, false);
+            const uint32_t w[4] = {odd ? pa : wa, odd ? pb : wb, odd ? wa : pa, odd ? wb : pb};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) keep[r] = ((w[r] >> (16 * odd)) & 0xFFFFu) >= P.drop.thresh;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = __builtin_fmaf(sc[u][t][r], scale2, kb[u]);
+            const float p = __builtin_amdgcn_exp2f(v - l2v[t][r]);
+            const float dpv = keep[r] ? dp[u][t][r] : 0.f;
+            sc[u][t][r] = keep[r] ? p : 0.f;
+            dp[u][t][r] = p * (dpv - dlv[t][r]);
+          }
+        }
+        fp[u] = v2_pack(sc[u][0], sc[u][1]);
+        fs[u] = v2_pack(dp[u][0], dp[u][1]);
+        // dS^T[key][q]: the lane's four queries of either tile are contiguous — one 8-byte write per tile
+        *(bf16x4*)(ds_row[u] + t0 * 16) = bf16x4{fs[u][0], fs[u][1], fs[u][2], fs[u][3]};
+        if (t0 + 1 < n_tq) *(bf16x4*)(ds_row[u] + t0 * 16 + 16) = bf16x4{fs[u][4], fs[u][5], fs[u][6], fs[u][7]};
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      const bf16x8 to = v2_frag_tr(img1, t0, d * 16, lane), tq = v2_frag_tr(img0, t0, d * 16, lane);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        dv[u][d] = mfma_bf16(to, fp[u], dv[u][d]);
+        dk[u][d] = mfma_bf16(tq, fs[u], dk[u][d]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  static_assert(ND == 4, "rows4_exchange: 64-column rows");
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const Row32 kv = rows4_exchange(dk[u], a.scale * ik), vv = rows4_exchange(dv[u], ik);
+    if (key[u] < S) {
+      bf16_t* krow = dqkv + (int64_t)key[u] * gld + D + 16 * g;
+      bf16_t* vrow = dqkv + (int64_t)key[u] * gld + 2 * D + 16 * g;
+      *(bf16x8*)krow = kv.a;
+      *(bf16x8*)(krow + 8) = kv.b;
+      *(bf16x8*)vrow = vv.a;
+      *(bf16x8*)(vrow + 8) = vv.b;
+    }
+  }
+}
+
+// The thread index through an empty asm: what is derived from the result is recomputed where it is used instead of being
+// hoisted out of the item loop and kept — the hoisted LDS / global offsets of all four sections of v5's loop were what
+// pushed it past 256 registers, and a scratch reload (a vector-memory instruction) drags s_waitcnt vmcnt(0) behind it.
+__device__ __forceinline__ int v5_opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+// One int through the scalar cache (uniform address, memory no kernel of this library writes while it runs).  Behind the first
+// global store of a kernel the compiler reads such tables with vector loads (the scalar cache is not coherent with them) and
+// s_waitcnt vmcnt(0) — which in v5's loop would also wait for every store and request in flight, three times per item.
+__device__ __forceinline__ int v5_sload(const int* p) {
+  int v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+  return v;
+}
+
+template <int HD, bool DROP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_v5_kernel(AttnParams P, int rows_img, int ldq, int n_items) {
+  constexpr int ND = HD / 16, NCH = 4;         // 16-byte chunks per thread and tensor: rows_img * 8 <= 4 * 512 (host check)
+  static_assert(HD == 64, "staging assumes 8 chunks per row");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const mdt_attn_fwd_args& a = P.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int SL = a.S, D = a.H * HD;
+  const int64_t tld = a.pos_stride * a.ld_qkv, dld = a.pos_stride * P.ld_dout, old_ = a.pos_stride * a.ld_out, gld = a.pos_stride * P.ld_dqkv;
+  bf16_t* img0 = (bf16_t*)smem;                       // Q, then K
+  bf16_t* img1 = img0 + rows_img * V2_LD;              // dO
+  float* s_kb = (float*)(img1 + rows_img * V2_LD);
+  float* s_lse = s_kb + rows_img;
+  float* s_delta = s_lse + rows_img;
+  bf16_t* dsT = (bf16_t*)(s_delta + rows_img);         // [16 * tiles][ldq]: dS^T, key-major
+  const float ik = DROP ? P.drop.inv_keep : 1.0f, rik = 1.0f / ik;
+
+  // an item = (sequence, head); everything about it is uniform over the workgroup
+  int seq, h, S, n_t, rows_live, q_rows;
+  int64_t row0;
+  auto item_of = [&](int it_) {
+    const int it = __builtin_amdgcn_readfirstlane(it_);      // uniform: keeps the index loads below on the scalar unit (no vmcnt)
+    const int si = it / a.H;
+    h = it - si * a.H;
+    seq = a.seq_ids ? v5_sload(a.seq_ids + si) : si;
+    if (a.seq_offsets) {
+      const int o0 = v5_sload(a.seq_offsets + seq), o1 = v5_sload(a.seq_offsets + seq + 1);
+      S = o1 - o0;
+      row0 = o0;
+    } else {
+      S = a.S;
+      row0 = (int64_t)seq * a.seq_stride;
+    }
+    n_t = (S + 15) >> 4;
+    rows_live = ((n_t + 1) >> 1) * 32;
+    if (rows_live > rows_img || S <= 0) { S = 0; n_t = 0; rows_live = 0; }      // longer than this launch's bound (s_cap) / empty: nothing to do
+    q_rows = (a.q_limit > 0 && ((a.q_limit + 15) & ~15) < S) ? ((a.q_limit + 15) & ~15) : S;   // rows the forward computed
+  };
+  // the registers an item arrives in
+  bf16x8 cq[NCH], cg[NCH], co[NCH];
+  float lv = 0.f;
+  KeyBytes kbv{1, 0};
+  bf16x8 wk[2][HD / 32], wv[2][HD / 32];
+  auto request_rows = [&](int tid) {           // unconditional, clamped: see v2_stage_req
+    if (S > 0) {
+      const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * a.ld_qkv + h * HD;
+      const bf16_t* dout = (const bf16_t*)P.dout + row0 * P.ld_dout + h * HD;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        const int e = tid + j * 512, r = e >> 3, c8 = e & 7;
+        const int rc = r < S ? r : S - 1;
+        cq[j] = *(const bf16x8*)(qkv + rc * tld + c8 * 8);
+        cg[j] = *(const bf16x8*)(dout + rc * dld + c8 * 8);
+      }
+      const int ti = tid < rows_live ? tid : 0;
+      lv = a.lse[((int64_t)seq * a.H + h) * SL + (ti < q_rows ? ti : q_rows - 1)];
+      BiasCtx bc{seq, h, S, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
+      kbv = key_only_bias_req(bc, ti, qkv);
+    }
+  };
+  auto request_frags = [&](int tid) {          // + the O chunks
+    if (S > 0) {
+      const int lane = tid & 63, wave = tid >> 6;
+      const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * a.ld_qkv + h * HD;
+      const bf16_t* outp = (const bf16_t*)a.out + row0 * a.ld_out + h * HD;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        const int e = tid + j * 512, r = e >> 3, c8 = e & 7;
+        const int ro = r < q_rows ? r : q_rows - 1;
+        co[j] = *(const bf16x8*)(outp + ro * old_ + c8 * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) {
+          wk[u][ks] = v2_frag_glb(qkv + D, tld, S, (wave + 8 * u) * 16, ks * 32, lane);      // rows clamp to S - 1: a tile past n_t reads valid memory
+          wv[u][ks] = v2_frag_glb(qkv + 2 * D, tld, S, (wave + 8 * u) * 16, ks * 32, lane);
+        }
+    }
+  };
+
+  int it = blockIdx.x;
+  if (it >= n_items) return;
+  item_of(it);
+  request_rows(tid);
+  request_frags(tid);
+  for (;;) {
+    // ---- the item whose registers have arrived: stage it
+    const int cS = S, c_nt = n_t, c_rows = rows_live, c_qrows = q_rows, c_seq = seq, c_h = h;
+    const int64_t c_row0 = row0;
+    const int tid1 = v5_opaque(tid);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int e = tid1 + j * 512, r = e >> 3, c8 = e & 7;
+      if (e < c_rows * 8) {        // whole waves (c_rows * 8 is a multiple of 256)
+        const bf16x8 z = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        const bf16x8 gv = r < cS ? cg[j] : z;
+        *(bf16x8*)(img0 + r * V2_LD + c8 * 8) = r < cS ? cq[j] : z;
+        *(bf16x8*)(img1 + r * V2_LD + c8 * 8) = gv;
+        float de = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) de += (float)co[j][k] * (float)gv[k];
+        de += __shfl_xor(de, 1, 64);
+        de += __shfl_xor(de, 2, 64);
+        de += __shfl_xor(de, 4, 64);
+        if (c8 == 0) s_delta[r] = r < c_qrows ? de * rik : 0.f;
+      }
+    }
+    if (tid1 < c_rows) {
+      BiasCtx bc{c_seq, c_h, cS, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
+      s_kb[tid1] = key_only_bias_of(bc, tid1, kbv);
+      s_lse[tid1] = (tid1 >= c_qrows || lv == -INFINITY) ? INFINITY : lv * LOG2E;
+    }
+    // the K / V fragments count as arrived HERE on every path: phase 1 runs under a wave-uniform branch, and where the paths
+    // meet again the compiler's wait bookkeeping keeps the worst case — it then waited for this item's dK / dV stores before
+    // writing K to LDS
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int ks = 0; ks < HD / 32; ++ks) asm volatile("" ::"v"(wk[u][ks]), "v"(wv[u][ks]));
+    __syncthreads();
+    const int nxt = it + (int)gridDim.x;
+    const bool more = nxt < n_items;
+    bf16_t* dqkv = (bf16_t*)P.dqkv + c_row0 * P.ld_dqkv + c_h * HD;
+    const int n_tq = (a.q_limit > 0 && ((a.q_limit + 15) >> 4) < c_nt) ? (a.q_limit + 15) >> 4 : c_nt;
+    // ---- phase 1 (keys on lanes): this wave's key tiles wave and wave + 8
+    const int lane1 = v5_opaque(lane);
+    if (wave + 8 < c_nt) v5_phase1<HD, DROP, 2>(P, img0, img1, s_kb, s_lse, s_delta, dsT, ldq, wk, wv, wave, lane1, cS, SL, c_seq * a.H + c_h, n_tq, dqkv, gld, D, ik);
+    else if (wave < c_nt) v5_phase1<HD, DROP, 1>(P, img0, img1, s_kb, s_lse, s_delta, dsT, ldq, wk, wv, wave, lane1, cS, SL, c_seq * a.H + c_h, n_tq, dqkv, gld, D, ik);
+    __syncthreads();   // every dS^T tile is in LDS; the Q / dO images are free
+    // K goes where Q was, from the fragment registers (see v4)
+    const int tid2 = v5_opaque(tid), lane2 = tid2 & 63;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (wave + 8 * u < c_nt) {
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) *(bf16x8*)(img0 + ((wave + 8 * u) * 16 + (lane2 & 15)) * V2_LD + ks * 32 + 8 * (lane2 >> 4)) = wk[u][ks];
+      }
+    // ---- everything the next item reads is requested here — its K / V fragments into the registers just written out — and
+    // arrives under phase 2, the barriers and the other workgroups' phases (carrying its 48 chunk registers through phase 1
+    // as well spilled: a scratch reload is a vector-memory instruction, and the s_waitcnt vmcnt(0) behind it also waits
+    // for every store and request issued before)
+    if (more) { item_of(nxt); request_rows(tid2); request_frags(tid2); }
+    __syncthreads();
+    // ---- phase 2 (queries on lanes): dQ^T = K^T dS^T
+    const int n_pair_k = (c_nt + 1) >> 1;
+    const int lane3 = v5_opaque(lane);
+    for (int qt = wave; qt < n_tq; qt += 8) {
+      const int q = qt * 16 + (lane3 & 15);
+      f32x4 dq[ND];
+#pragma unroll
+      for (int d = 0; d < ND; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int pk = 0; pk < n_pair_k; ++pk) {
+        const bf16x8 fs = v2_frag_tr_ld(dsT, ldq, 2 * pk, qt * 16, lane3, 2 * pk + 1 < c_nt);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) dq[d] = mfma_bf16(v2_frag_tr(img0, 2 * pk, d * 16, lane3), fs, dq[d]);
+      }
+      const Row32 qv = rows4_exchange(dq, a.scale * ik);
+      if (q < cS) {
+        bf16_t* orow = dqkv + (int64_t)q * gld + 16 * (lane3 >> 4);
+        *(bf16x8*)orow = qv.a;
+        *(bf16x8*)(orow + 8) = qv.b;
+      }
+    }
+    if (!more) break;
+    it = nxt;
+    __syncthreads();   // the images and dS^T are free for the next item
+  }
+}
+
 // LDS of the one-pass kernel for rows of up to S keys; 0 = does not fit
 static size_t v4_lds_bytes(int S, int* rows_img, int* ldq) {
   const int n_t = (S + 15) / 16;
@@ -1053,6 +1368,31 @@ static int launch_v3(hipStream_t st, const AttnParams& p) {
         attr_set = true;
       }
       const int n_t = (cap + 15) / 16;
+      // long rows (one workgroup per CU by LDS) in launches of many rounds: the persistent form (a launch of two or three rounds
+      // gains nothing from it: 0.95 x at 37 x 12 and 300 x 12 items); MDT_ATTN_ONEPASS=4 keeps v4 there, 5 takes v5 at any size
+      if (n_t > 8 && op != 4 && rows_img * 8 <= 4 * 512 && n_t <= 16 && ((int64_t)p.f.H * p.f.nseq >= 8 * 256 || op == 5)) {
+        auto k5 = attn_bwd_v5_kernel<64, DROP>;
+        static bool attr5 = false;
+        if (!attr5) {
+          if (hipFuncSetAttribute((const void*)k5, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("attention_bwd_v5: cannot reserve 160 KiB of LDS");
+            return MDT_ERR_LAUNCH;
+          }
+          attr5 = true;
+        }
+        static int cus = 0;
+        if (!cus) {
+          int dev = 0;
+          hipDeviceProp_t prop;
+          if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+          if (cus <= 0) cus = 256;
+        }
+        const int64_t n_items = (int64_t)p.f.H * p.f.nseq;
+        const int grid = (int)(n_items < cus ? n_items : cus);
+        hipLaunchKernelGGL(k5, dim3(grid), 512, lds4, st, p, rows_img, ldq, (int)n_items);
+        return check_launch("attention_bwd_v5");
+      }
       const int waves = n_t <= 4 ? 4 : n_t <= 8 ? 8 : 16;
       if (rows_img * 8 > 2 * waves * 64 || n_t > waves) {      // two 16-byte chunks per thread and image, one key tile per wave
         set_error("attention_bwd_v4: %d image rows for %d waves", rows_img, waves);

@@ -741,6 +741,45 @@ def test_attention_backward_one_pass_equals_two_pass(ops, S, ragged, qlim, p, mo
     assert ((grads[0] - grads[1]).norm() / grads[0].norm()).item() <= 1e-3
 
 
+# ----------------------------------------------------------------------------- persistent one-pass backward (long rows)
+@pytest.mark.parametrize("S,ragged,qlim,p", [(201, False, 0, 0.1), (197, True, 0, 0.3), (130, False, 0, 0.0), (208, True, 16, 0.2)])
+def test_attention_backward_persistent_is_bit_identical(ops, S, ragged, qlim, p, monkeypatch):
+    """csrc/attention_v2.hip attn_bwd_v5 (8 waves walking (sequence, head) items, two key tiles per wave through one
+    query-pair loop, the next item requested under phase 2) against attn_bwd_v4 (one workgroup per item): same operands,
+    same summation orders, same dropout counters — bit-identical gradients.  360 items on at most 256 workgroups, so some
+    walk two items; the ragged cases mix rows of 1 ... S tokens (items of one to thirteen key tiles) in one launch."""
+    from multimodaldiscussiontransformer_amd import _lib as L
+    nseq, H, hd = 30, 12, 64
+    g = torch.Generator().manual_seed(S + 3)
+    kw = dict(drop_p=p, drop_seed=23)
+    if ragged:
+        lens = torch.randint(1, S + 1, (nseq,), generator=g, dtype=torch.int32)
+        lens[0], lens[1], lens[2] = S, 1, 17
+        off = torch.zeros(nseq + 1, dtype=torch.int32)
+        off[1:] = torch.cumsum(lens, 0)
+        rows = int(off[-1])
+        kw["seq_offsets"] = dev(off)
+    else:
+        rows = nseq * S
+    if qlim:
+        kw["q_limit"] = qlim
+    qkv = dev((torch.randn(rows, 3 * H * hd, generator=g) * 0.7).to(torch.bfloat16))
+    dout = dev(torch.randn(rows, H * hd, generator=g).to(torch.bfloat16))
+    out, lse = ops.attention_fwd(qkv, nseq, S, H, **kw)
+    grads = []
+    try:
+        for v in ("4", "5"):
+            monkeypatch.setenv("MDT_ATTN_ONEPASS", v)
+            L.reload_env()
+            d, _ = ops.attention_bwd(dout, qkv, out, lse, nseq, S, H, **kw)
+            grads.append(d.float().cpu())
+    finally:
+        monkeypatch.delenv("MDT_ATTN_ONEPASS")
+        L.reload_env()
+    assert torch.isfinite(grads[1]).all()
+    assert torch.equal(grads[0], grads[1])
+
+
 # ----------------------------------------------------------------------------- ragged attention in length bins
 @pytest.mark.parametrize("p,qlim", [(0.0, 0), (0.2, 0), (0.1, 20)])
 def test_attention_length_bins_equal_single_launch(ops, p, qlim):
