@@ -1072,7 +1072,6 @@ __device__ __forceinline__ void v5_phase1(const AttnParams& P, const bf16_t* img
           dp[u][t] = mfma_bf16(ao, wv[u][ks], dp[u][t]);   // dP[q][key]
         }
       }
-    __builtin_amdgcn_sched_barrier(0);
     bf16x8 fp[NU], fs[NU];
     {
       f32x4 l2v[2], dlv[2];
@@ -1122,7 +1121,6 @@ __device__ __forceinline__ void v5_phase1(const AttnParams& P, const bf16_t* img
         dk[u][d] = mfma_bf16(tq, fs[u], dk[u][d]);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
   static_assert(ND == 4, "rows4_exchange: 64-column rows");
 #pragma unroll
