@@ -111,15 +111,17 @@ __device__ __forceinline__ float col_sum(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
-// Output rows leave as 32 contiguous bytes per lane.  An accumulator set x[d'][r] of a 16-row x 64-column result holds,
-// in lane (g, c), columns 16 d' + 4 g + r of row c: four 8-byte pieces 32 bytes apart, and a wave store of one piece
-// writes 32-byte fragments of 16 different rows (sixteen quarter-filled 128-byte lines per instruction; the stores of the
-// one-pass backward ran at 2.8-3.5 TB/s for it).  A 4 x 4 exchange among the four 16-lane rows of the wave — piece d' of
-// row g trades places with piece g of row d': v_permlane32_swap on the pairs (0, 2), (1, 3), then v_permlane16_swap on
-// (0, 1), (2, 3) — leaves lane (g, c) with columns 16 g ... 16 g + 15 of row c in order, which go out as two 16-byte
-// stores (the same bytes in a quarter of the fragments: measured 4.6 TB/s).  All 64 lanes must be active.
-// Inline asm with s_nop 1 for the reason given in gemm_epilogue.hpp (builtin folded by hipcc; VALU write -> swap hazard).
+// Output rows leave as 16-byte vectors, 64 contiguous bytes of a row per wave instruction.  An accumulator set x[d'][r] of a
+// 16-row x 64-column result holds, in lane (g, c), columns 16 d' + 4 g + r of row c: four 8-byte pieces 32 bytes apart, and a
+// wave store of one piece writes 32-byte fragments of 16 different rows (sixteen quarter-filled 128-byte lines per
+// instruction; the stores of the one-pass backward ran at 2.8-3.5 TB/s for it).  One v_permlane16_swap per register between
+// the column tiles 2 f and 2 f + 1 (odd 16-lane rows of the first trade places with even rows of the second — the exchange
+// of gemm_epilogue.hpp) leaves lane (g, c) with columns 32 f + 16 (g & 1) + 8 (g >> 1) ... + 7 of row c: vector a (f = 0) and
+// vector b (f = 1), at element offset rows4_off(g) and 32 further on — the four lanes of a row write 64 contiguous bytes in
+// either instruction.  All 64 lanes must be active.  Inline asm with s_nop 1 for the reason given in gemm_epilogue.hpp
+// (the builtin is folded by hipcc; VALU write -> swap hazard).
 struct Row32 { bf16x8 a, b; };
+__device__ __forceinline__ int rows4_off(int g) { return 16 * (g & 1) + 8 * (g >> 1); }
 __device__ __forceinline__ Row32 rows4_exchange(const f32x4 (&x)[4], float scale) {
   uint32_t lo[4], hi[4];
 #pragma unroll
@@ -129,13 +131,9 @@ __device__ __forceinline__ Row32 rows4_exchange(const f32x4 (&x)[4], float scale
     lo[d] = u.x;
     hi[d] = u.y;
   }
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo[0]), "+v"(lo[2]));
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo[1]), "+v"(lo[3]));
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(hi[0]), "+v"(hi[2]));
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(hi[1]), "+v"(hi[3]));
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo[0]), "+v"(lo[1]));
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo[2]), "+v"(lo[3]));
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(hi[0]), "+v"(hi[1]));
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo[2]), "+v"(lo[3]));
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(hi[2]), "+v"(hi[3]));
   Row32 r;
   r.a = __builtin_bit_cast(bf16x8, uint4{lo[0], hi[0], lo[1], hi[1]});
@@ -284,9 +282,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_v2_kernel(AttnParams P) {
     static_assert(ND == 4, "rows4_exchange: 64-column rows");
     const Row32 ov = rows4_exchange(o, inv);      // inv is per query = per lane column c: the same in the four lanes that trade
     if (q < S) {
-      bf16_t* orow = (bf16_t*)a.out + (row0 + (int64_t)q * a.pos_stride) * a.ld_out + h * HD + 16 * g;
+      bf16_t* orow = (bf16_t*)a.out + (row0 + (int64_t)q * a.pos_stride) * a.ld_out + h * HD + rows4_off(g);
       *(bf16x8*)orow = ov.a;
-      *(bf16x8*)(orow + 8) = ov.b;
+      *(bf16x8*)(orow + 32) = ov.b;
     }
   }
 }
@@ -972,12 +970,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     static_assert(ND == 4, "rows4_exchange: 64-column rows");
     const Row32 kv = rows4_exchange(dk, a.scale * ik), vv = rows4_exchange(dv, ik);
     if (kok) {
-      bf16_t* krow = dqkv + (int64_t)key * gld + D + 16 * g;
-      bf16_t* vrow = dqkv + (int64_t)key * gld + 2 * D + 16 * g;
+      bf16_t* krow = dqkv + (int64_t)key * gld + D + rows4_off(g);
+      bf16_t* vrow = dqkv + (int64_t)key * gld + 2 * D + rows4_off(g);
       *(bf16x8*)krow = kv.a;
-      *(bf16x8*)(krow + 8) = kv.b;
+      *(bf16x8*)(krow + 32) = kv.b;
       *(bf16x8*)vrow = vv.a;
-      *(bf16x8*)(vrow + 8) = vv.b;
+      *(bf16x8*)(vrow + 32) = vv.b;
     }
   }
   // K goes where Q was — from the registers that already hold it: the K fragments of the waves ARE the rows of K (lane
@@ -1003,9 +1001,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     }
     const Row32 qv = rows4_exchange(dq, a.scale * ik);
     if (q < S) {
-      bf16_t* orow = dqkv + (int64_t)q * gld + 16 * g;
+      bf16_t* orow = dqkv + (int64_t)q * gld + rows4_off(g);
       *(bf16x8*)orow = qv.a;
-      *(bf16x8*)(orow + 8) = qv.b;
+      *(bf16x8*)(orow + 32) = qv.b;
     }
   }
 }
@@ -1127,12 +1125,12 @@ __device__ __forceinline__ void v5_phase1(const AttnParams& P, const bf16_t* img
   for (int u = 0; u < NU; ++u) {
     const Row32 kv = rows4_exchange(dk[u], a.scale * ik), vv = rows4_exchange(dv[u], ik);
     if (key[u] < S) {
-      bf16_t* krow = dqkv + (int64_t)key[u] * gld + D + 16 * g;
-      bf16_t* vrow = dqkv + (int64_t)key[u] * gld + 2 * D + 16 * g;
+      bf16_t* krow = dqkv + (int64_t)key[u] * gld + D + rows4_off(g);
+      bf16_t* vrow = dqkv + (int64_t)key[u] * gld + 2 * D + rows4_off(g);
       *(bf16x8*)krow = kv.a;
-      *(bf16x8*)(krow + 8) = kv.b;
+      *(bf16x8*)(krow + 32) = kv.b;
       *(bf16x8*)vrow = vv.a;
-      *(bf16x8*)(vrow + 8) = vv.b;
+      *(bf16x8*)(vrow + 32) = vv.b;
     }
   }
 }
@@ -1312,9 +1310,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       const Row32 qv = rows4_exchange(dq, a.scale * ik);
       if (q < cS) {
-        bf16_t* orow = dqkv + (int64_t)q * gld + 16 * (lane3 >> 4);
+        bf16_t* orow = dqkv + (int64_t)q * gld + rows4_off(lane3 >> 4);
         *(bf16x8*)orow = qv.a;
-        *(bf16x8*)(orow + 8) = qv.b;
+        *(bf16x8*)(orow + 32) = qv.b;
       }
     }
     if (!more) break;
