@@ -608,14 +608,17 @@ static int dispatch(hipStream_t st, const AttnParams& p) {
     if (a.hd == 64 && !dense_only && !switches().attn_v1) {
       if (!BWD) return attention_v2_dispatch(st, p, false);              // forward: register-resident P
       // backward, measured at C2 shapes (profiles/round1_attention_v2.txt): S <= 112 -> whole-row v2,
-      // longer sequences -> chunked v3 / one-pass v4; tiny graphs (S <= 80, structural bias) stay on the LDS-scratch kernel below
+      // longer sequences -> chunked v3 / one-pass v4; tiny graphs and short rows (S <= 80) stay on the LDS-scratch kernel below
       const char* force = switches().attn_bwd[0] ? switches().attn_bwd : nullptr;      // MDT_ATTN_BWD = "v1" | "v2" | "v3" for A/B runs
       const bool drop = a.drop_p > 0.f;                // with dropout the whole-row v2 falls to 1 wave / SIMD: chunked v3 wins
       if (BWD && a.S > 256 && !force) return attention_v3_bwd_dispatch(st, p);   // ViT-L/14: 4 + 257 tokens
-      // (round 3: only with structural bias — plain rows of up to 80 tokens take the one-pass v4 like longer ones: 749 -> 250 us
-      // on 2048 ragged sequences of 10-64 tokens)
-      const bool v1 = force ? !strcmp(force, "v1") : (a.S <= 80 && st_bias);
-      const bool v2 = (force ? !strcmp(force, "v2") : !drop) && a.S <= 112;
+      // (round 3: sending plain rows of up to 80 tokens to the one-pass v4 instead is 3 x faster — 749 -> 225 us on 2048 ragged
+      // sequences of 10-64 tokens — but v4 forms delta = rowsum(dO o O) from the bf16 output where this kernel sums P o dP in
+      // fp32, and on the C4F fixture (query / key gradients at 1e-3 of the block's gradient scale) that noise is 1.8 of the
+      // remnant: the routing stays until v4 forms delta itself)
+      const bool v1 = force ? !strcmp(force, "v1") : a.S <= 80;
+      // the whole-row v2 backward knows nothing of q_limit (rows the forward skipped have no lse): those launches take v3 / v4
+      const bool v2 = (force ? !strcmp(force, "v2") : (!drop && a.q_limit == 0)) && a.S <= 112;
       if (!v1) return v2 ? attention_v2_dispatch(st, p, true) : attention_v3_bwd_dispatch(st, p);
     }
     if (a.hd == 64) return st_bias ? dispatch_nt<bf16_t, 64, true, BWD>(st, p) : dispatch_nt<bf16_t, 64, false, BWD>(st, p);

@@ -1015,18 +1015,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 // arithmetic + 100 us of stores = the 530 us it took; the two halves never overlap.  This form keeps the LDS layout and the
 // arithmetic of v4 and changes who waits for whom:
 //   * 8 waves of up to 256 registers instead of 16 of 128; a workgroup walks items blockIdx.x, + gridDim.x, ... and requests
-//     the NEXT item's Q / dO / O chunks, lse, mask bytes and K / V fragments (into the fragment registers, 82 VGPRs in all)
-//     as soon as phase 1 has written K to LDS: they arrive under phase 2 and the barriers, and no workgroup launch, kernel
-//     argument fetch or store drain stands between two items;
+//     the NEXT item's Q / dO / O chunks, lse and mask bytes (50 VGPRs) right after the barrier that ends the current item's
+//     staging — they arrive under phase 1 — and its K / V fragments into the fragment registers as soon as phase 1 has
+//     written K to LDS (under phase 2); no workgroup launch, kernel argument fetch or store drain stands between two items;
 //   * a wave owns key tiles w and w + 8 and runs both through ONE query-pair loop: the Q / dO fragments (row-major for
 //     S, dP; transposed for dV, dK), lse and delta vectors are read from LDS once for the two tiles — half the LDS read
 //     traffic per MFMA of v4, which together with the VALU stream is what bounds phase 1.
 // Operand values, summation orders and dropout decisions are those of v4: the outputs are bit-identical to it.
-// Measured (profiles/round3_experiments/attn_v5_persistent.log, 512 x 197 x 12 heads): 543 -> 526 us with dropout 0.3, 467 ->
-// 405 us without.  Where its time goes (phases switched off one by one): phase 1 310 us (195 without dropout: the two waves
-// of a SIMD issue its VALU stream at ~80 % of the pipe — the counter RNG is 37 % of it), phase 2 31, staging / barriers / K
-// 67, and ~105 us of the next item's requests still exposed: they are issued after phase 1, because their 82 registers on top
-// of phase 1's 233 do not fit, and phase 2 is too short to cover them.
+// Measured (profiles/round3_experiments/attn_v5_persistent.log, 512 x 197 x 12 heads, one call): 547 -> 487 us with dropout
+// 0.3, 469 -> 375 us without; never slower than v4 on launches of one to three rounds.  The first version requested the next
+// item only after phase 1 (it spilled otherwise) and gained 3 %: what spilled were loop-invariant offsets hoisted out of the
+// item loop, not the chunks (v5_opaque), and a scratch reload drags s_waitcnt vmcnt(0) behind it.  Where the time of that
+// first version went (phases switched off one by one): phase 1 310 us (195 without dropout), phase 2 31, staging / barriers
+// / K 67, requests exposed 105.
 template <int HD, bool DROP, int NU>
 __device__ __forceinline__ void v5_phase1(const AttnParams& P, const bf16_t* img0, const bf16_t* img1, const float* s_kb, const float* s_lse,
                                           const float* s_delta, bf16_t* dsT, int ldq, const bf16x8 (&wk)[2][HD / 32], const bf16x8 (&wv)[2][HD / 32],
@@ -1198,12 +1199,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (S > 0) {
       const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * a.ld_qkv + h * HD;
       const bf16_t* dout = (const bf16_t*)P.dout + row0 * P.ld_dout + h * HD;
+      const bf16_t* outp = (const bf16_t*)a.out + row0 * a.ld_out + h * HD;
 #pragma unroll
       for (int j = 0; j < NCH; ++j) {
         const int e = tid + j * 512, r = e >> 3, c8 = e & 7;
         const int rc = r < S ? r : S - 1;
         cq[j] = *(const bf16x8*)(qkv + rc * tld + c8 * 8);
         cg[j] = *(const bf16x8*)(dout + rc * dld + c8 * 8);
+        co[j] = *(const bf16x8*)(outp + (r < q_rows ? r : q_rows - 1) * old_ + c8 * 8);
       }
       const int ti = tid < rows_live ? tid : 0;
       lv = a.lse[((int64_t)seq * a.H + h) * SL + (ti < q_rows ? ti : q_rows - 1)];
@@ -1211,17 +1214,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       kbv = key_only_bias_req(bc, ti, qkv);
     }
   };
-  auto request_frags = [&](int tid) {          // + the O chunks
+  auto request_frags = [&](int tid) {
     if (S > 0) {
       const int lane = tid & 63, wave = tid >> 6;
       const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * a.ld_qkv + h * HD;
-      const bf16_t* outp = (const bf16_t*)a.out + row0 * a.ld_out + h * HD;
-#pragma unroll
-      for (int j = 0; j < NCH; ++j) {
-        const int e = tid + j * 512, r = e >> 3, c8 = e & 7;
-        const int ro = r < q_rows ? r : q_rows - 1;
-        co[j] = *(const bf16x8*)(outp + ro * old_ + c8 * 8);
-      }
+
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -1274,6 +1271,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
     const int nxt = it + (int)gridDim.x;
     const bool more = nxt < n_items;
+    if (more) { item_of(nxt); request_rows(v5_opaque(tid)); }      // Q / dO chunks, lse, mask bytes: arrive under phase 1
     bf16_t* dqkv = (bf16_t*)P.dqkv + c_row0 * P.ld_dqkv + c_h * HD;
     const int n_tq = (a.q_limit > 0 && ((a.q_limit + 15) >> 4) < c_nt) ? (a.q_limit + 15) >> 4 : c_nt;
     // ---- phase 1 (keys on lanes): this wave's key tiles wave and wave + 8
@@ -1289,11 +1287,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int ks = 0; ks < HD / 32; ++ks) *(bf16x8*)(img0 + ((wave + 8 * u) * 16 + (lane2 & 15)) * V2_LD + ks * 32 + 8 * (lane2 >> 4)) = wk[u][ks];
       }
-    // ---- everything the next item reads is requested here — its K / V fragments into the registers just written out — and
-    // arrives under phase 2, the barriers and the other workgroups' phases (carrying its 48 chunk registers through phase 1
-    // as well spilled: a scratch reload is a vector-memory instruction, and the s_waitcnt vmcnt(0) behind it also waits
-    // for every store and request issued before)
-    if (more) { item_of(nxt); request_rows(tid2); request_frags(tid2); }
+    // ---- the next item's K / V fragments, into the registers just written out: they arrive under phase 2
+    if (more) request_frags(tid2);
     __syncthreads();
     // ---- phase 2 (queries on lanes): dQ^T = K^T dS^T
     const int n_pair_k = (c_nt + 1) >> 1;
@@ -1364,9 +1359,8 @@ static int launch_v3(hipStream_t st, const AttnParams& p) {
         attr_set = true;
       }
       const int n_t = (cap + 15) / 16;
-      // long rows (one workgroup per CU by LDS) in launches of many rounds: the persistent form (a launch of two or three rounds
-      // gains nothing from it: 0.95 x at 37 x 12 and 300 x 12 items); MDT_ATTN_ONEPASS=4 keeps v4 there, 5 takes v5 at any size
-      if (n_t > 8 && op != 4 && rows_img * 8 <= 4 * 512 && n_t <= 16 && ((int64_t)p.f.H * p.f.nseq >= 8 * 256 || op == 5)) {
+      // long rows (one workgroup per CU by LDS): the persistent form; MDT_ATTN_ONEPASS=4 keeps v4 there
+      if (n_t > 8 && op != 4 && rows_img * 8 <= 4 * 512 && n_t <= 16) {
         auto k5 = attn_bwd_v5_kernel<64, DROP>;
         static bool attr5 = false;
         if (!attr5) {
