@@ -49,6 +49,11 @@ def run(name, nseq, S, lens=None, p=0.3, q_limit=0):
 
 
 torch.manual_seed(0)
+run("bert 2048 x 104 padded", 2048, 104)
+tl = torch.randint(10, 103, (2048,), generator=torch.Generator().manual_seed(1)).to(torch.int32)
+run("bert 2048 ragged 10-102", 2048, 104, lens=tl)
+tl2 = torch.randint(65, 103, (1000,), generator=torch.Generator().manual_seed(2)).to(torch.int32)
+run("bert 1000 ragged 65-102", 1000, 104, lens=tl2)
 run("vit 512 x 197", 512, 197)
 run("vit 512 x 197", 512, 197, p=0.0)
 run("vit 37 x 197 (tail)", 37, 197)
