@@ -40,7 +40,7 @@ def agg(kind, counter):
             continue
         n = r["Kernel_Name"]
         key = "other"
-        for k in ("gemm_f8_w4", "gemm_bf16_w4s", "gemm_bf16_w4p", "gemm_bf16_pp256p", "gemm_bf16_pp256", "gemm_bf16_tile128", "attn_bwd_v4", "attn_bwd_v3", "attn_fwd_v2", "layernorm_bwd",
+        for k in ("gemm_f8_w4", "gemm_bf16_w4s", "gemm_bf16_w4p", "gemm_bf16_pp256p", "gemm_bf16_pp256", "gemm_bf16_tile128", "attn_bwd_v5", "attn_bwd_v4", "attn_bwd_v3", "attn_fwd_v2", "layernorm_bwd",
                   "layernorm_fwd", "colsum"):
             if k in n:
                 key = k

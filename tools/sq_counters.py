@@ -13,7 +13,7 @@ import sys
 tag = sys.argv[1]
 rnd = sys.argv[2] if len(sys.argv) > 2 else "round1"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAM = ("gemm_f8_w4", "gemm_bf16_w4s", "gemm_bf16_w4p", "gemm_bf16_pp256p", "gemm_bf16_pp256", "gemm_bf16_tile128", "attn_bwd_v4", "attn_bwd_v3", "attn_fwd_v2", "layernorm_bwd", "layernorm_fwd", "colsum")
+FAM = ("gemm_f8_w4", "gemm_bf16_w4s", "gemm_bf16_w4p", "gemm_bf16_pp256p", "gemm_bf16_pp256", "gemm_bf16_tile128", "attn_bwd_v5", "attn_bwd_v4", "attn_bwd_v3", "attn_fwd_v2", "layernorm_bwd", "layernorm_fwd", "colsum")
 
 
 def durations():
