@@ -131,3 +131,61 @@ def test_light_epilogues_use_no_scratch(w4_kernels):
     f8 = {n: b for n, b in scratch.items() if "gemm_f8_w4" in n}
     light8 = {n: b for n, b in f8.items() if _specialised(n) in (0, 1, 4)}      # plain, bias, residual
     assert len(f8) >= 8 and len(light8) >= 3 and all(b == 0 for b in light8.values()), f8
+
+
+# ----------------------------------------------------------------------------- attn_bwd_v5 (persistent one-pass attention backward)
+@pytest.fixture(scope="module")
+def v5_kernels(tmp_path_factory):
+    if not (os.path.exists(OBJDUMP) and os.path.exists(READELF)):
+        pytest.skip("llvm-objdump / llvm-readelf not available")
+    from multimodaldiscussiontransformer_amd import build as B
+    B.build()
+    tmp = tmp_path_factory.mktemp("isa_attn")
+    obj = shutil.copy(os.path.join(B.HERE, "build", "attention_v2.o"), tmp / "attention_v2.o")
+    subprocess.run([OBJDUMP, "--offloading", str(obj)], cwd=tmp, capture_output=True, text=True, check=True)
+    co = [f for f in os.listdir(tmp) if "amdgcn" in f]
+    assert len(co) == 1, os.listdir(tmp)
+    co = str(tmp / co[0])
+    dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout.split("\n")
+    kernels, cur = {}, None
+    for l in dis:
+        m = re.match(r"^[0-9a-f]+ <(\w+)>:", l)
+        if m:
+            cur = kernels.setdefault(m.group(1), []) if "attn_bwd_v5_kernel" in m.group(1) else None
+            continue
+        if cur is not None:
+            t = l.split("//")[0].strip()
+            if t:
+                cur.append(t)
+    notes = subprocess.run([READELF, "--notes", co], capture_output=True, text=True, check=True).stdout
+    scratch = {}
+    for blk in re.split(r"\n\s+- \.", notes):
+        n = re.search(r"\.name:\s+(\S+)", blk) or re.search(r"^name:\s+(\S+)", blk, re.M)
+        ps = re.search(r"private_segment_fixed_size:\s+(\d+)", blk)
+        if n and ps:
+            scratch[n.group(1)] = int(ps.group(1))
+    assert len(kernels) == 2, sorted(kernels)          # with and without dropout
+    return kernels, scratch
+
+
+def test_persistent_attention_backward_keeps_its_requests_in_flight(v5_kernels):
+    """csrc/attention_v2.hip attn_bwd_v5: the next item's rows are requested after the staging barrier and must stay in flight
+    through phase 1, its fragments through phase 2.  What broke that while the kernel was written, each visible in the ISA:
+    scratch (a reload is a vector-memory instruction and is followed by s_waitcnt vmcnt(0), which also waits for every store
+    and request issued before it); vector loads of seq_ids / seq_offsets behind the first store (same wait); a full drain
+    before K is written to LDS.  So: no scratch at all, and between the first workgroup barrier of the item loop and the
+    end of the kernel no s_waitcnt vmcnt(0) except the ones that wait for the mask bytes (a branch the hot launches skip:
+    they follow a global_load_ubyte) and the one that ends the next item's staging (right before the loop's first barrier)."""
+    kernels, scratch = v5_kernels
+    for name, body in kernels.items():
+        assert scratch.get(name, 0) == 0, (name, scratch.get(name))
+        assert not any(t.startswith("scratch_") for t in body), name
+        bars = [i for i, t in enumerate(body) if t.startswith("s_barrier")]
+        assert len(bars) == 4, (name, len(bars))       # staged | dS^T complete | K written | item done
+        # the loop body in program order: from the first barrier to the end; the staging of the next item sits before it
+        drains = [i for i in range(bars[0], len(body)) if re.match(r"s_waitcnt vmcnt\(0\)", body[i])]
+        for i in drains:
+            near = body[max(0, i - 4):i]
+            assert any(t.startswith("global_load_ubyte") for t in near), (name, i, body[max(0, i - 6):i + 1])
+        # index tables by scalar loads only
+        assert not any(t.startswith("global_load_dword ") for t in body[bars[1]:bars[2]]), name

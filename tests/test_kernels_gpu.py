@@ -742,7 +742,8 @@ def test_attention_backward_one_pass_equals_two_pass(ops, S, ragged, qlim, p, mo
 
 
 # ----------------------------------------------------------------------------- persistent one-pass backward (long rows)
-@pytest.mark.parametrize("S,ragged,qlim,p", [(201, False, 0, 0.1), (197, True, 0, 0.3), (130, False, 0, 0.0), (208, True, 16, 0.2)])
+@pytest.mark.parametrize("S,ragged,qlim,p", [(201, False, 0, 0.1), (197, True, 0, 0.3), (130, False, 0, 0.0), (208, True, 16, 0.2),
+                                               (150, "mask", 0, 0.2)])
 def test_attention_backward_persistent_is_bit_identical(ops, S, ragged, qlim, p, monkeypatch):
     """csrc/attention_v2.hip attn_bwd_v5 (8 waves walking (sequence, head) items, two key tiles per wave through one
     query-pair loop, the next item requested under phase 2) against attn_bwd_v4 (one workgroup per item): same operands,
@@ -752,6 +753,13 @@ def test_attention_backward_persistent_is_bit_identical(ops, S, ragged, qlim, p,
     nseq, H, hd = 30, 12, 64
     g = torch.Generator().manual_seed(S + 3)
     kw = dict(drop_p=p, drop_seed=23)
+    if ragged == "mask":          # padded layout: a key mask per sequence (one sequence fully visible, one with a single key)
+        ragged = False
+        km = (torch.rand(nseq, S, generator=g) < 0.8).to(torch.uint8)
+        km[:, 0] = 1
+        km[0] = 1
+        km[1, 1:] = 0
+        kw["key_mask"] = dev(km)
     if ragged:
         lens = torch.randint(1, S + 1, (nseq,), generator=g, dtype=torch.int32)
         lens[0], lens[1], lens[2] = S, 1, 17
