@@ -789,13 +789,14 @@ def test_attention_backward_persistent_is_bit_identical(ops, S, ragged, qlim, p,
 
 
 # ----------------------------------------------------------------------------- ragged attention in length bins
-@pytest.mark.parametrize("p,qlim", [(0.0, 0), (0.2, 0), (0.1, 20)])
-def test_attention_length_bins_equal_single_launch(ops, p, qlim):
+@pytest.mark.parametrize("p,qlim,S", [(0.0, 0, 104), (0.2, 0, 104), (0.1, 20, 104), (0.2, 0, 200)])
+def test_attention_length_bins_equal_single_launch(ops, p, qlim, S):
     """mdt_attn_fwd_args.seq_ids / s_cap: a ragged set processed as one launch per length bin (short comments with the
     small kernels) gives bit-identical out / lse / dQKV — lse rows and dropout counters are those of the sequence's own
-    index, whichever launch computes it."""
+    index, whichever launch computes it.  S = 200: the longest bin (13 tiles) goes through the persistent backward, which
+    walks the bin's sequence ids itself."""
     from multimodaldiscussiontransformer_amd.data.packer import RaggedText
-    nseq, S, H, hd = 37, 104, 3, 64
+    nseq, H, hd = 37, 3, 64
     g = torch.Generator().manual_seed(5)
     lens = torch.randint(1, S + 1, (nseq,), generator=g, dtype=torch.int32)
     lens[3], lens[4], lens[5] = S, 64, 65
