@@ -326,6 +326,8 @@ def test_fp8_producer_quantised_operands_equal_stand_alone_passes(monkeypatch):
     lg_f, g_f, fused_n, gemms_f = run(True)
     lg_s, g_s, fused_0, gemms_s = run(False)
     assert fused_n > 0 and fused_0 == 0 and gemms_f == gemms_s, (fused_n, fused_0, gemms_f, gemms_s)
+    print(f"[fp8 fused vs stand-alone] logits sums {float(lg_f.double().sum()):.10f} / {float(lg_s.double().sum()):.10f}, max |diff| {float((lg_f - lg_s).abs().max()):.3e}, "
+          f"first rows {lg_f[0].tolist()} / {lg_s[0].tolist()}")
     assert torch.equal(lg_f, lg_s)
     # gradients: the split-K weight gradients add their slabs with fp32 atomics in whatever order they finish — equal up to that
     assert float((g_f.double() - g_s.double()).norm() / g_s.double().norm()) < 1e-5
