@@ -11,6 +11,7 @@ for i in $(seq 1 12); do
   if grep -q " failed" gpurun_out/flake_one.log; then n=$((n+1)); [ $n -eq 1 ] && cp gpurun_out/flake_one.log gpurun_out/flake_first_failure.log; fi
 done
 echo "failures: $n of 12" >> $out
+timeout -k 10 300 python tools/gemm_determinism.py 200 >> $out 2>&1      # the same launches repeated: any difference is a race
 cat $out | sort | uniq -c
 [ -f gpurun_out/flake_first_failure.log ] && grep -n "^E \|Mismatch\|mismatch\|Greatest" gpurun_out/flake_first_failure.log | head -30
 true
