@@ -4,6 +4,7 @@
 # suite only, tests/test_fp8_gpu.py::test_fp8_producer_quantised_operands_equal_stand_alone_passes.  This keeps the evidence of a
 # failing run: the first failing log in full.
 out=gpurun_out/flake_hunt.log; : > $out
+echo "box $(cat /sys/class/drm/card*/device/unique_id 2>/dev/null | head -1)" >> $out
 n=0
 for i in $(seq 1 12); do
   timeout -k 10 120 python -m pytest tests/test_dropout_gpu.py -m gpu -x -q -k "saved_derivative" > gpurun_out/flake_one.log 2>&1
