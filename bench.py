@@ -41,6 +41,40 @@ import sys
 import time
 from types import SimpleNamespace
 
+
+
+def _self_launch():
+    """`python bench.py --gpus N` typed as is (N > 1, no RANK in the environment): start the N ranks with torch.distributed.run as a
+    FRESH CHILD process — before torch or the package are imported here, so this process never touches the GPU and nothing is
+    exec'ed over an initialised one — pass its output through and leave with its exit code.  Mirrors the reference's
+    `fairseq-train --distributed-world-size N` (run_train.sh:52) spawning its own ranks."""
+    n = 1
+    argv = sys.argv[1:]
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1 or "RANK" in os.environ:
+        return
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = str(s_.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (the host driver supports nothing else)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + argv
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+if __name__ == "__main__":
+    _self_launch()
+
 import numpy as np
 import torch
 
@@ -51,6 +85,9 @@ if os.environ.get("MDT_SINGLE_DEVICE") == "1":
     # cross-queue event waits of the step then never resolve (observed: both ranks stuck in the first gradient
     # all-reduce).  HIP's default of 4 per process is the safe value when processes share a GPU.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+FOREIGN_LIBRARY = "--foreign-library" in sys.argv        # an A/B arm on a library built from other sources (tools/ab_libs.sh): said in the line
+if not FOREIGN_LIBRARY:
+    os.environ["MDT_BENCH_OFFICIAL"] = "1"               # _lib refuses MDT_SKIP_SOURCE_HASH: a line of record comes from the csrc/ beside it
 import multimodaldiscussiontransformer_amd  # noqa: E402,F401  (sets GPU_MAX_HW_QUEUES before the first device call)
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0
@@ -140,14 +177,14 @@ def flops_per_comment(L=100, nb=4, P=197, D=768, F=3072, Lb=6, Lf=6, G=6, N=64, 
     return text + rho * image + graph_tree / N + head
 
 
-def host_cores() -> int:
+def host_cores(share: int = 1) -> int:
     """CPU share of this process (the GPU box gives 16 cores per GPU; os.cpu_count() reports the
-    whole host and oversubscribing it makes torch-CPU crawl)."""
+    whole host and oversubscribing it makes torch-CPU crawl).  ``share``: ranks on this node dividing the affinity set."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(n, 16))
+    return max(1, min(n // max(1, share), 16))
 
 
 class GemmTimer:
@@ -442,6 +479,7 @@ def main():
                     help="fp8 (BASELINE.json configs[4]): bf16 model with per-tensor-scaled e4m3 / e5m2 operands in the blocks' big GEMMs "
                          "(multimodaldiscussiontransformer_amd/fp8.py; --fp8-sites picks which)")
     ap.add_argument("--fp8-sites", default=None, help="preset (all | fast4 | grads) or comma list of fp8 sites; default: MDT_FP8_SITES or all")
+    ap.add_argument("--foreign-library", action="store_true", help="A/B arm: allow MDT_SKIP_SOURCE_HASH=1 (a library built from other sources); the line says so")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
     ap.add_argument("--no-selfcheck", action="store_true", help="skip the numerics guard that runs before the warm-up")
@@ -464,12 +502,27 @@ def main():
         args.num_fusion_layers = cfg["layers"] // 2 - 1
 
     import torch.distributed as dist
-    torch.set_num_threads(host_cores())
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # the ranks of a node share its host cores: each takes its share for torch-CPU work (index building, the packer's helpers)
+    torch.set_num_threads(max(1, host_cores(share=int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("MDT_BENCH_LAUNCH_ONLY") == "1":
+        # entry-point rehearsal for a box without a GPU (tests/test_ddp_cpu.py): the ranks meet over gloo, count themselves with one
+        # all-reduce and rank 0 prints a line of the contract's shape — proves that `python bench.py --gpus N` as typed gets N
+        # ranks to a working process group; nothing is measured
+        dist.init_process_group("gloo")
+        seen = torch.ones(1)
+        dist.all_reduce(seen)
+        if rank == 0:
+            print(json.dumps({"metric": "discussion-tree comments/sec fwd+bwd", "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "launch_only": True, "distributed": {"world": world, "world_seen_by_backend": int(seen.item()), "backend_seen": "gloo",
+                                                                    "torch_cpu_threads_per_rank": torch.get_num_threads()}}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # rehearsal switches (not for measurements): MDT_SINGLE_DEVICE=1 puts every rank on cuda:0 and MDT_DIST_BACKEND=gloo
     # replaces RCCL, so the whole multi-process flow can be exercised on a one-GPU box
     if os.environ.get("MDT_SINGLE_DEVICE") == "1":
@@ -634,20 +687,35 @@ def main():
     if dp.bucketer.active and not args.no_verify_exchange:
         vb = last
 
+        # the check repeats ONE step three times and compares the gradients: the step must leave nothing behind that the
+        # next repetition would see — no weight update (opt) and, with fp8 operands, the delayed scales / running maxima
+        # put back to what they were (end_of_step derives the next scales from this batch's maxima)
+        f8_keep = None if fp8_state is None else [t.clone() for t in (fp8_state.scale, fp8_state.inv, fp8_state.amax)]
+        opt_keep, opt = opt, None
+
         def same_step():
             torch.manual_seed(4242)                 # dropout-site seeds come from the CPU generator (engine.Tape.next_seed)
+            if f8_keep is not None:
+                for t, k in zip((fp8_state.scale, fp8_state.inv, fp8_state.amax), f8_keep):
+                    t.copy_(k)
             step(vb)
             torch.cuda.synchronize()
         exchange_check = dp.verify_exchange(same_step)
+        opt = opt_keep
         if not exchange_check["ok"]:
             raise SystemExit(f"gradient exchange self-check failed on rank {rank}: {exchange_check}")
-    tot = torch.tensor([dt, float(sum(comments))], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([dt, float(sum(comments)), packer_host_ms[1] if packer_host_ms else 0.0, packer_ms[1] if packer_ms else 0.0, t_issue * 1e3],
+                       dtype=torch.float64, device="cuda")
+    per_rank_host = None
     if dist.is_initialized():
         both = [torch.zeros_like(tot) for _ in range(world)]
         dist.all_gather(both, tot)
         dt = max(float(b[0]) for b in both)
         total_comments = sum(float(b[1]) for b in both)
         per_rank_comments = [int(b[1]) for b in both]
+        # host-side contention between the ranks of one node (each packs, uploads and enqueues on its own cores): worst batch per rank
+        per_rank_host = dict(packer_host_ms_max=[round(float(b[2]), 2) for b in both], packer_h2d_ms_max=[round(float(b[3]), 2) for b in both],
+                             host_issue_ms=[round(float(b[4]), 2) for b in both], torch_cpu_threads_per_rank=torch.get_num_threads())
     else:
         total_comments = float(sum(comments))
         per_rank_comments = [int(total_comments)]
@@ -719,6 +787,8 @@ def main():
             "roofline": roofline,
             "selfcheck": "skipped" if (args.no_selfcheck or not low) else dict(kernels="passed", **(model_check or {})),
         }
+        if FOREIGN_LIBRARY:
+            out["foreign_library"] = True
         if fp8_state is not None:
             out["fp8"] = dict(gemm_launches_total=fp8_state.gemms, sites=len(fp8_state.sites), formats="e4m3 activations / weights, e5m2 gradients",
                               scaling="per tensor, delayed (margin 2), device-resident", where=",".join(fp8_state.site_names),
@@ -726,7 +796,7 @@ def main():
                               kernel="v_mfma_f32_16x16x128_f8f6f4 (gemm_f8_w4) where K % 128 == 0, else 16x16x32 fp8 (gemm_bf16_pp256p F8)")
         if dist_diag is not None:
             out["distributed"] = dict(world=world, backend=backend, comments_per_rank=per_rank_comments, variable_trees=bool(args.variable_trees),
-                                      exchange_check=exchange_check, **dist_diag)
+                                      exchange_check=exchange_check, per_rank_host=per_rank_host, **dist_diag)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import torch
 
@@ -96,7 +97,13 @@ EXPORTS = tuple(_SIGS)
 
 
 class MdtError(RuntimeError):
-    pass
+    status = 0
+
+
+class MdtUnsupported(MdtError):
+    """MDT_ERR_UNSUPPORTED: a valid request this build has no kernel for (callers may choose another route); every other
+    status is a contract violation or a launch failure and is never to be retried silently."""
+    status = -2
 
 
 def _load():
@@ -112,8 +119,13 @@ def _load():
     if lib.mdt_abi_version() != 1:
         raise ImportError("libmdt_hip.so ABI version mismatch")
     # the .so is git-ignored and travels to the GPU box prebuilt: it must be the build of the csrc/ next to it
-    if os.environ.get("MDT_SKIP_SOURCE_HASH") != "1" and os.path.isdir(os.path.join(_HERE, "csrc")):
-        from .build import source_hash
+    skip = os.environ.get("MDT_SKIP_SOURCE_HASH") == "1"
+    if skip and ("pytest" in sys.modules or os.environ.get("MDT_BENCH_OFFICIAL") == "1"):
+        # the override exists for in-call A/B runs of two builds (tools/ab_libs.sh): a test run or a bench line of record
+        # must never inherit it
+        raise ImportError("MDT_SKIP_SOURCE_HASH=1 is refused under pytest and bench.py (bench.py --foreign-library for an A/B arm)")
+    from .build import source_hash, hash_inputs_present
+    if not skip and hash_inputs_present():      # an installed copy without csrc/ or include/ has nothing to compare against
         built, here = lib.mdt_source_hash().decode(), source_hash()
         if built != here:
             raise ImportError(f"{LIB_PATH} was built from other sources (library {built[:16]}, csrc/ {here[:16]}): rebuild with "
@@ -143,7 +155,9 @@ def enable_dynamic_tile_queue(device="cuda"):
 
 def check(status: int, what: str = ""):
     if status != 0:
-        raise MdtError(f"{what}: status {status}: {lib.mdt_last_error_string().decode()}")
+        e = (MdtUnsupported if status == -2 else MdtError)(f"{what}: status {status}: {lib.mdt_last_error_string().decode()}")
+        e.status = status
+        raise e
 
 
 def dt(t: torch.Tensor) -> int:

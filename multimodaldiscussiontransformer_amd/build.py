@@ -31,6 +31,10 @@ def source_hash() -> str:
     return h.hexdigest()
 
 
+def hash_inputs_present() -> bool:
+    return os.path.isdir(CSRC) and os.path.exists(os.path.join(HERE, "..", "include", "mdt_hip.h"))
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -70,7 +74,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
     text = f'extern "C" const char* mdt_source_hash(void) {{ return "{digest}"; }}\n'
     if not os.path.exists(stamp_src) or open(stamp_src).read() != text or not os.path.exists(stamp_obj):
         open(stamp_src, "w").write(text)
-        run([os.environ.get("CXX", "g++"), "-O1", "-fPIC", "-c", stamp_src, "-o", stamp_obj])
+        run([hipcc, "-x", "c++", "-O1", "-fPIC", "-c", stamp_src, "-o", stamp_obj])     # host-only unit, same compiler as the rest
         jobs.append(None)
     if force or jobs or _stale(OUT, objs + [stamp_obj]):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + [stamp_obj])

@@ -173,14 +173,14 @@ class Fp8State:
             return ops.gemm_fp8(x8, w8, inv_x, inv_w, a_format=fmt, **kw)
         j = self.sites.get(q8_site)
         if j is not None and FUSED_Q and q8_site[0] in self.site_names and q8_site not in self.no_q8:
-            from ._lib import MdtError
+            from ._lib import MdtUnsupported
             out8 = torch.empty(x.shape[0], n_out, dtype=torch.uint8, device=x.device)
             try:
                 out = ops.gemm_fp8(x8, w8, inv_x, inv_w, a_format=fmt, q8_out=out8, q8_format=ops.FP8_E5M2 if q8_grad else ops.FP8_E4M3,
                                    q8_scale=self.scale[j:j + 1], q8_amax=self.amax[j:j + 1], **kw)
                 self.fused_outputs += 1
                 return out, (out8, self.inv[j:j + 1])
-            except MdtError:
+            except MdtUnsupported:               # only "no kernel writes the copy": a launch error or a contract violation propagates
                 self.no_q8.add(q8_site)          # e.g. MDT_GEMM_F8W=0: nothing writes the copy; do not ask again
         return ops.gemm_fp8(x8, w8, inv_x, inv_w, a_format=fmt, **kw), None
 

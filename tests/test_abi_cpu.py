@@ -69,3 +69,16 @@ def test_native_packer_large_random_trees(lib):
     with pytest.raises(Exception):
         from multimodaldiscussiontransformer_amd.data.packer import pack_structure
         pack_structure([np.array([-1, 2, 0])], 5)      # child before parent
+
+
+def test_source_hash_override_is_refused_under_pytest_and_bench():
+    """MDT_SKIP_SOURCE_HASH=1 (two builds against one csrc/, tools/ab_libs.sh) must not leak into a test run or a bench line of record."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MDT_SKIP_SOURCE_HASH="1")
+    for pre in ("import pytest", "import os; os.environ['MDT_BENCH_OFFICIAL'] = '1'"):
+        r = subprocess.run([sys.executable, "-c", pre + "; import multimodaldiscussiontransformer_amd._lib"], cwd=root, env=env, capture_output=True, text=True)
+        assert r.returncode != 0 and "MDT_SKIP_SOURCE_HASH=1 is refused" in r.stderr, r.stderr[-500:]
+    r = subprocess.run([sys.executable, "-c", "import multimodaldiscussiontransformer_amd._lib"], cwd=root, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-500:]

@@ -10,6 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _free_port():
     s = socket.socket()
@@ -319,3 +321,26 @@ def test_exchange_self_check_gloo_world2():
         p.join(timeout=60)
     for rank, status, info in out:
         assert status == "ok", f"rank {rank}: {info}"
+
+
+def test_bench_gpus_n_as_typed_starts_n_ranks():
+    """`python3 bench.py --gpus N` — the form the driver's N = 1 line uses, typed with N > 1 and no RANK in the environment —
+    must start its own ranks (a fresh torch.distributed.run child, bench._self_launch) instead of asking to be launched.
+    MDT_BENCH_LAUNCH_ONLY=1 stops every rank after the process group has counted itself (no GPU here)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["MDT_BENCH_LAUNCH_ONLY"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["distributed"]["world_seen_by_backend"] == 2 and out["steps"] == 3
+    # a failing rank's exit code comes back through the launcher
+    env["MDT_BENCH_LAUNCH_ONLY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus=2", "--config", "nonsense"], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0
