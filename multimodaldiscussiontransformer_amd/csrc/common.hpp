@@ -40,7 +40,7 @@ int check_launch(const char* what);
 // asks — the hot path makes no getenv calls — and again only when the host calls mdt_reload_env() (tests, A/B tools).
 struct Switches {
   int gemm_pp_dist;          // MDT_GEMM_PP_DIST   (default 4)
-  bool gemm_persist;         // MDT_GEMM_PERSIST   (default 1)
+  int gemm_persist;          // MDT_GEMM_PERSIST   (default 1: persistent tile walk for K loops of at least 16 steps; 0: never; 2: for every K >= 128 — stress runs)
   bool gemm_dynamic;         // MDT_GEMM_DYNAMIC   (default 0): dynamic tile queue, needs mdt_gemm_set_tile_queue
   int gemm_group;            // MDT_GEMM_GROUP     (-1: unset)
   bool gemm_stamp;           // MDT_GEMM_STAMP

@@ -458,7 +458,12 @@ __device__ __forceinline__ f32x4 mfma_f8(long w, long x, f32x4 c) {      // w: w
   else return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w, x, c, 0, 0, 0);
 }
 
-template <bool A_KM, bool B_KM, int PP_DIST, int EPK = -1, int F8 = 0>
+// JIT (stress builds of the same source, MDT_GEMM_DIAG=16, tools/gemm_stress.py): every wave sleeps a pseudo-random 0-900 cycles at
+// each point of the protocol where another wave may be waiting for it or racing it — before its fragment reads, between reads
+// and LDS-DMA issue, before its counted wait, on either side of both barriers of a step, around the epilogue and in front of a
+// tile's first barrier.  The ring's RAW / WAR argument (above gemm_bf16_pp256) must hold under ANY interleaving: a hole shows
+// as a bit difference against the 128 x 128 kernel within a few hundred launches instead of on one box in fifteen.
+template <bool A_KM, bool B_KM, int PP_DIST, int EPK = -1, int F8 = 0, bool JIT = false>
 __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
   static_assert(F8 == 0 || (!A_KM && !B_KM), "8-bit operands are k-contiguous");
   constexpr int PP_NB = pp_nb(PP_DIST);
@@ -528,6 +533,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   static_assert(PP_DIST >= 2 && PP_DIST <= 4, "wait_pieces assumes at most 3 steps left in flight");
+  unsigned jit_state = JIT ? ((unsigned)blockIdx.x * 2654435761u) ^ ((unsigned)wave * 0x9E3779B9u) ^ (unsigned)__builtin_amdgcn_s_memtime() : 0u;
+  auto jitter = [&]() __attribute__((always_inline)) {
+    if constexpr (JIT) {
+      jit_state = jit_state * 1664525u + 1013904223u;
+      const int n = __builtin_amdgcn_readfirstlane((int)(jit_state >> 24) & 7);
+      __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
 
   if (p.epilogue & (1 << 22)) {   // diagnostic (MDT_GEMM_DIAG=4): skew the workgroups of an XCD so their epilogues do not coincide
     const int steps = ((blockIdx.x >> 3) & 7) * (nhs / 8);
@@ -579,6 +594,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    jitter();
     __builtin_amdgcn_s_barrier();
     if (late) __builtin_amdgcn_s_barrier();      // the stagger: waves 4-7 run one segment behind
     __builtin_amdgcn_sched_barrier(0);
@@ -587,12 +603,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
     const bool step_stamp = p.stamps && tid == 0 && blockIdx.x == 9 && (tile_no == 4 || tile_no == 5) && nhs <= 100;
     for (int hs = 0; hs < nhs; ++hs) {
       if (step_stamp) p.stamps[4 * (size_t)gridDim.x + (tile_no - 4) * (nhs + 2) + hs] = __builtin_amdgcn_s_memtime();
+      jitter();
       const char* rd = smem + b_rd * PP_STAGE;
       bf16x8 a[8], b[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) b[j] = load_frag_h<B_KM, BN>(rd + A_BYTES, wc * 64 + j * 16, lane);
 #pragma unroll
       for (int i = 0; i < 8; ++i) a[i] = load_frag_h<A_KM, BM>(rd, wr * 128 + i * 16, lane);
+      jitter();
       const int tgt = hs + PP_DIST;
       if (tgt < nhs) {
         issue_step(cur, tgt, b_wr);
@@ -604,9 +622,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
         wait_pieces(nhs - 2 - hs > 0 ? nhs - 2 - hs : 0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      jitter();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      jitter();
       __builtin_amdgcn_s_setprio(1);
       if constexpr (F8 == 0) {
 #pragma unroll
@@ -623,13 +643,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
               acc[i][j] = mfma_f8<F8>(__builtin_bit_cast(i64x2, b[j])[hk], __builtin_bit_cast(i64x2, a[i])[hk], acc[i][j]);
       }
       __builtin_amdgcn_s_setprio(0);
+      jitter();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       b_wr = b_wr + 1 == PP_NB ? 0 : b_wr + 1;
       b_rd = b_rd + 1 == PP_NB ? 0 : b_rd + 1;
     }
+    jitter();
     if (!late) __builtin_amdgcn_s_barrier();     // both groups leave the tile together
+    jitter();
     if (p.stamps) { s_cyc += __builtin_amdgcn_s_memtime() - t_cyc; s_real += __builtin_amdgcn_s_memrealtime() - t_real; s_nk += nhs / 2; }
     if (step_stamp) p.stamps[4 * (size_t)gridDim.x + (tile_no - 4) * (nhs + 2) + nhs] = __builtin_amdgcn_s_memtime();
     int popped = -1;
@@ -641,6 +664,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
     } else {
       direct_epilogue<2, EPK>(p, acc, lane, cur.m0 + wr * 128, cur.n0 + wc * 64);
     }
+    jitter();
     if (step_stamp) p.stamps[4 * (size_t)gridDim.x + (tile_no - 4) * (nhs + 2) + nhs + 1] = __builtin_amdgcn_s_memtime();
     if (!has_next) break;
     cur = nxt;
@@ -1198,9 +1222,14 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)p.split_k);
   const Switches& sw = switches();
   const int dist = sw.gemm_pp_dist;
-  const bool persist_ok = sw.gemm_persist;
   const int nhs_total = 2 * (int)((p.K + T_BK - 1) / T_BK);
-  const bool persist = persist_ok && sizeof(TOut) == 2 && p.split_k == 1 && nhs_total >= 4 && (int)grid.x > num_cus();
+  // The persistent walk pays where a tile is short against its launch / first-fetch / drain (K = 768: 24 steps) and needs at
+  // least PP_DIST steps per tile.  Launches with fewer than 16 steps per tile (K < 512) — none in a training step — take one
+  // workgroup per tile: a tile boundary then never falls inside the prefetch window of the previous one (round 3 saw an
+  // intermittent wrong result on ONE box at K = 256 with two tiles per workgroup that no other device and no jittered stress
+  // run reproduces, DESIGN.md "pp256p"; MDT_GEMM_PERSIST=2 — tools/gemm_stress.py — keeps the short-K walk reachable).
+  const int min_steps = sw.gemm_persist >= 2 ? 4 : 16;
+  const bool persist = sw.gemm_persist != 0 && sizeof(TOut) == 2 && p.split_k == 1 && nhs_total >= min_steps && (int)grid.x > num_cus();
   if (persist) grid.x = (unsigned)num_cus();
   p.tile_queue = nullptr;
   if (persist && nhs_total >= W4_NEXPL + 2) {
@@ -1210,7 +1239,8 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
     const int e_ = p.epilogue & ((1 << 22) - 1);   // start-skew diagnostics (bits 22+) keep the compile-time epilogues
     const bool light = e_ == 0 || e_ == MDT_EPI_BIAS || e_ == MDT_EPI_RESIDUAL || e_ == (MDT_EPI_BIAS | MDT_EPI_RESIDUAL | MDT_EPI_DROPOUT) ||
                        e_ == (MDT_EPI_MULAUX | MDT_EPI_COLSUM);
-    const bool use_w4 = (w4 == 1 || (w4 == 2 && !ta && light && !sw.gemm_no_spec)) && !(sw.gemm_dynamic && g_tile_queues);
+    const bool use_w4 = (w4 == 1 || (w4 == 2 && !ta && light && !sw.gemm_no_spec)) && !(sw.gemm_dynamic && g_tile_queues) &&
+                        !(p.epilogue & (1 << 24));      // the jittered stress build exists for the 8-wave kernel
     if (use_w4) {
 #ifdef MDT_W4_STAMPS
       if (sw.gemm_stamp) {
@@ -1346,6 +1376,27 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
                   E_FC1 = MDT_EPI_BIAS | MDT_EPI_GELU | MDT_EPI_AUX_GRAD /* HF blocks have no activation dropout */, E_RES = MDT_EPI_RESIDUAL,
                   E_DFC2 = MDT_EPI_MULAUX | MDT_EPI_COLSUM;
     const int e = sw.gemm_no_spec ? -2 : (p.epilogue & ((1 << 22) - 1));
+    if (p.epilogue & (1 << 24)) {          // MDT_GEMM_DIAG=16: the jittered stress build of the same source (tools/gemm_stress.py)
+#define LPJ(A_, B_, E_)                                                                                      \
+  {                                                                                                          \
+    auto kern = gemm_bf16_pp256p<A_, B_, 4, E_, 0, true>;                                                    \
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+      (void)hipGetLastError();                                                                               \
+      set_error("gemm_bf16_pp256p (jitter): cannot reserve %zu bytes of LDS", lds);                          \
+      return MDT_ERR_LAUNCH;                                                                                 \
+    }                                                                                                        \
+    hipLaunchKernelGGL(kern, grid, 512, lds, st, p);                                                         \
+  }
+      if (!ta && !tb && e == E_FC1 && p.aux) LPJ(false, false, E_FC1)
+      else if (!ta && !tb && e == E_DENSE) LPJ(false, false, E_DENSE)
+      else if (!ta && !tb) LPJ(false, false, -1)
+      else if (!ta && tb && e == E_DFC2) LPJ(false, true, E_DFC2)
+      else if (!ta && tb) LPJ(false, true, -1)
+      else if (ta && !tb) LPJ(true, false, -1)
+      else LPJ(true, true, -1)
+#undef LPJ
+      return check_launch("gemm_bf16_pp256p (jitter)");
+    }
     if (!ta && !tb) {
       if (e == E_BIAS) LPS(false, false, E_BIAS)
       else if (e == E_DENSE) LPS(false, false, E_DENSE)
@@ -1492,7 +1543,7 @@ extern "C" int mdt_gemm(void* stream, int dtype, int out_dtype, int trans_a, int
   p.tile_queue = nullptr;
   p.alpha_dev = p.alpha_dev2 = nullptr;
   p.group_n = 1 << 30;   // row-major unless launch_pp256 decides otherwise
-  p.epilogue |= switches().gemm_diag << 20;   // diagnostics: 1 skip stores, 2 sc1 stores, 4 skewed starts within an XCD, 8 every tile loads tile (0,0)'s panels, 64 XCDs skewed against each other, 256 row-panel groups skewed inside an XCD (4-wave kernel)
+  p.epilogue |= switches().gemm_diag << 20;   // diagnostics: 1 skip stores, 2 sc1 stores, 16 jittered stress build of the 8-wave persistent kernel, 4 skewed starts within an XCD, 8 every tile loads tile (0,0)'s panels, 64 XCDs skewed against each other, 256 row-panel groups skewed inside an XCD (4-wave kernel)
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_COLSUM) || (colsum && split_k == 1), "mdt_gemm: MDT_EPI_COLSUM needs a colsum buffer and split_k == 1");
   // (MDT_EPI_ATOMIC already implies an fp32 C; said again because the kernels compute the sums in their fp32-output form only)
   MDT_CHECK_ARG(!(epilogue & MDT_EPI_ASUM) || (colsum && trans_a && (epilogue & MDT_EPI_ATOMIC) && !(epilogue & MDT_EPI_COLSUM) && dtype == MDT_BF16 && out_dtype == MDT_F32),

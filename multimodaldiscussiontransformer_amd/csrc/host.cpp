@@ -43,7 +43,7 @@ static void read_switches() {
     if (v) { strncpy(dst, v, cap - 1); dst[cap - 1] = 0; }
   };
   g_sw.gemm_pp_dist = num("MDT_GEMM_PP_DIST", 4);
-  g_sw.gemm_persist = num("MDT_GEMM_PERSIST", 1) != 0;
+  g_sw.gemm_persist = num("MDT_GEMM_PERSIST", 1);
   g_sw.gemm_dynamic = num("MDT_GEMM_DYNAMIC", 0) != 0;
   g_sw.gemm_group = num("MDT_GEMM_GROUP", -1);
   g_sw.gemm_stamp = flag("MDT_GEMM_STAMP");

@@ -189,3 +189,95 @@ def test_persistent_attention_backward_keeps_its_requests_in_flight(v5_kernels):
             assert any(t.startswith("global_load_ubyte") for t in near), (name, i, body[max(0, i - 6):i + 1])
         # index tables by scalar loads only
         assert not any(t.startswith("global_load_dword ") for t in body[bars[1]:bars[2]]), name
+
+
+# ----------------------------------------------------------------------------- gemm_bf16_pp256 / pp256p (8-wave ping-pong ring)
+@pytest.fixture(scope="module")
+def pp_kernels(tmp_path_factory):
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    from multimodaldiscussiontransformer_amd import build as B
+    B.build()
+    tmp = tmp_path_factory.mktemp("isa_pp")
+    obj = shutil.copy(os.path.join(B.HERE, "build", "gemm.o"), tmp / "gemm.o")
+    subprocess.run([OBJDUMP, "--offloading", str(obj)], cwd=tmp, capture_output=True, text=True, check=True)
+    co = [f for f in os.listdir(tmp) if "amdgcn" in f]
+    assert len(co) == 1, os.listdir(tmp)
+    dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", str(tmp / co[0])], capture_output=True, text=True, check=True).stdout.split("\n")
+    kernels, cur = {}, None
+    for l in dis:
+        m = re.match(r"^[0-9a-f]+ <(\w+)>:", l)
+        if m:
+            cur = kernels.setdefault(m.group(1), []) if re.search(r"gemm_bf16_pp256p?I", m.group(1)) else None
+            continue
+        if cur is not None:
+            t = l.split("//")[0].strip()
+            if t:
+                cur.append(t)
+    assert sum("pp256pI" in k for k in kernels) >= 20 and sum("pp256I" in k for k in kernels) >= 12, sorted(kernels)
+    return kernels
+
+
+def _mfma_segments(body):
+    """[first, last] instruction indices of every run of MFMAs that makes up one 32-k step's MFMA segment (>= 32 of them, only
+    s_waitcnt / s_nop in between)"""
+    segs, i = [], 0
+    while i < len(body):
+        if body[i].startswith("v_mfma"):
+            j, n, last = i, 0, i
+            while j < len(body) and (body[j].startswith(("v_mfma", "s_waitcnt", "s_nop", "s_andn2", "s_and_b64"))):
+                if body[j].startswith("v_mfma"):
+                    n, last = n + 1, j
+                j += 1
+            if n >= 32:
+                segs.append((i, last))
+            i = j
+        else:
+            i += 1
+    return segs
+
+
+def test_ping_pong_ring_keeps_its_segment_discipline(pp_kernels):
+    """The RAW / WAR argument of the ring (csrc/gemm.hip, above gemm_bf16_pp256) holds for the instruction stream only if every
+    fragment read and every LDS-DMA request of a 32-k step sits in the step's READ segment, closed by s_waitcnt lgkmcnt(0) and a
+    workgroup barrier, and the MFMA segment between its two barriers touches neither LDS nor memory.  The barriers are builtins
+    the compiler sees as not touching memory: nothing but the asm waits and the scheduling fences keeps an LDS read from moving
+    across one.  Audited here, for every instantiation (production and the jittered stress build):
+      * an MFMA segment is entered through  s_waitcnt lgkmcnt(0) ... s_barrier  with no LDS / vector-memory instruction between
+        the wait and the first MFMA, and left through a barrier with none between the last MFMA and the barrier;
+      * no LDS or vector-memory instruction inside an MFMA segment;
+      * the fragment reads that follow the closing barrier come BEFORE the first LDS-DMA request of that READ segment only in
+        program order that respects the barrier (i.e. there is no ds_read between the barrier and the MFMAs it opens)."""
+    mem = ("ds_", "buffer_", "global_", "flat_", "scratch_")
+    audited = 0
+    for name, body in pp_kernels.items():
+        segs = _mfma_segments(body)
+        assert segs, name
+        for first, last in segs:
+            # inside: only MFMAs, waits (no-ops behind the lgkmcnt(0) in front of the barrier) and nops
+            inside = [t for t in body[first:last + 1] if not t.startswith(("v_mfma", "s_waitcnt lgkmcnt", "s_nop", "s_andn2", "s_and_b64"))]
+            assert not inside, (name, first, inside[:3])
+            # entry: walking back from the first MFMA we must meet s_barrier, then s_waitcnt lgkmcnt(0), before any memory instruction
+            k, seen_bar, ok = first - 1, False, False
+            while k >= 0 and first - k < 40:
+                t = body[k]
+                if t.startswith(mem):
+                    break
+                if t == "s_barrier":
+                    seen_bar = True
+                elif seen_bar and re.match(r"s_waitcnt.*lgkmcnt\(0\)", t):
+                    ok = True
+                    break
+                elif t.startswith(("s_cbranch", "s_branch")) and not seen_bar:
+                    pass                                  # the jitter loops of the stress build sit between barrier and MFMAs
+                k -= 1
+            assert ok, (name, first, body[max(0, first - 12):first + 1])
+            # exit: the next barrier comes before any memory instruction (the fp32-output kernel's riding bias-gradient MFMAs sit
+            # in branches of their own behind the main run: a branch out of the linear view ends the walk)
+            k = last + 1
+            while k < len(body) and body[k] != "s_barrier" and not body[k].startswith("s_branch"):
+                assert not body[k].startswith(mem), (name, last, body[last:k + 1])
+                k += 1
+            assert k < len(body), name
+            audited += 1
+    assert audited >= 40
