@@ -100,6 +100,13 @@ CONFIGS = {
     # BASELINE.json configs[3]: BERT-large + ViT-L/14, 12 graph layers, 128-node deep threads
     "large": dict(dim=1024, heads=16, ffn=4096, layers=24, patch=14, image=224, trees=8, nodes=128, shape="deep",
                   name="mDT-large (BERT-large + ViT-L/14 split 12+12, 12 executed graph layers, D1024 H16 nb4 L100)"),
+    # the configuration the reference SHIPS (sample_run.sh:3 = `run_train.sh 8 4 5 2 2 0`; run_train.sh:41-65): 8 fusion layers
+    # (split 3 + 9), fusion and graph stacks of 2 (10 executed graph layers), graph FFN 768, --freeze_initial_encoders,
+    # --batch-size 12 x --update-freq 3, Adam.  A step here = ONE UPDATE: three micro-batches of 12 trees accumulate into the
+    # gradient arena, then the fused Adam step.  (The dataset's trees are private: 64-comment bushy trees stand in.)
+    "launch": dict(dim=768, heads=12, ffn=3072, layers=12, patch=16, image=224, trees=12, nodes=64, shape="bushy", fusion_layers=8,
+                   fusion_stack=2, graph_stack=2, update_freq=3, freeze=True, optimizer=True,
+                   name="mDT as launched by sample_run.sh:3 (BERT-base + ViT-B/16 split 3+9 frozen prefix, fusion / graph stacks of 2, 10 executed graph layers, graph FFN 768, D768 H12 nb4 L100)"),
 }
 
 
@@ -108,7 +115,7 @@ def base_args(a):
     return SimpleNamespace(
         num_atoms=512 * 9, num_in_degree=512, num_out_degree=512, num_edges=512 * 3, num_spatial=512, num_edge_dis=128,
         edge_type="multi_hop", multi_hop_max_dist=5, num_bottleneck_tokens=4, num_fusion_layers=a.num_fusion_layers,
-        num_fusion_stack=1, num_graph_stack=1, encoder_layers=4, encoder_embed_dim=c["dim"], encoder_ffn_embed_dim=c["dim"],
+        num_fusion_stack=c.get("fusion_stack", 1), num_graph_stack=c.get("graph_stack", 1), encoder_layers=4, encoder_embed_dim=c["dim"], encoder_ffn_embed_dim=c["dim"],
         encoder_attention_heads=c["heads"], dropout=a.dropout, attention_dropout=a.attention_dropout, act_dropout=a.act_dropout,
         encoder_normalize_before=True,
         pre_layernorm=False, apply_graphormer_init=False, activation_fn="gelu",
@@ -154,11 +161,19 @@ def code_state_hash() -> str:
 
 
 def flops_per_comment(L=100, nb=4, P=197, D=768, F=3072, Lb=6, Lf=6, G=6, N=64, Fg=768, rho=0.25, patch=16, lens=None,
-                      prune_last=False):
+                      prune_last=False, frozen_prefix=False):
     """Algorithmic forward FLOPs per comment.  ``lens``: valid-token counts of the comments when the
     text side runs ragged (the padded reference spends ``L`` tokens on every comment).  ``prune_last``: the last
     fusion layer runs its output projection and FFN only on the rows that are read afterwards (2 per comment, 1 per
-    image) — the reference computes (and discards) all of them."""
+    image) — the reference computes (and discards) all of them.  ``frozen_prefix`` (--freeze_initial_encoders): → the
+    forward + backward count per comment instead, with the frozen pre-fusion layers and the patch embedding counted ONCE
+    (their adjoint never runs) and everything else three times."""
+    if frozen_prefix:
+        kw = dict(L=L, nb=nb, P=P, D=D, F=F, Lf=Lf, G=G, N=N, Fg=Fg, rho=rho, patch=patch, lens=lens, prune_last=prune_last)
+        live = flops_per_comment(Lb=0, **kw)
+        whole = flops_per_comment(Lb=Lb, **kw)
+        patch_embed = rho * 2 * (P - 1) * (3 * patch * patch) * D
+        return 3 * (live - patch_embed) + (whole - live) + patch_embed
     def enc(S, kept=None):
         rows = S if kept is None else kept
         return 6 * S * D * D + 4 * S * S * D + rows * (2 * D * D + 4 * D * F)
@@ -499,7 +514,10 @@ def main():
     args.trees = args.trees or cfg["trees"]
     args.nodes = args.nodes or cfg["nodes"]
     if args.num_fusion_layers < 0:
-        args.num_fusion_layers = cfg["layers"] // 2 - 1
+        args.num_fusion_layers = cfg.get("fusion_layers", cfg["layers"] // 2 - 1)
+    args.freeze_initial_encoders = args.freeze_initial_encoders or cfg.get("freeze", False)
+    args.with_optimizer = args.with_optimizer or cfg.get("optimizer", False)
+    uf = cfg.get("update_freq", 1)                # micro-batches per step (run_train.sh:65 --update-freq)
 
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -569,7 +587,7 @@ def main():
     # one pool instead of 308 MB per batch.  With N > 1 the global batch of a step is dealt to the ranks by token cost
     # (trees_for_rank: the same fixed trees at every N unless --variable-trees).
     n_roof = max(1, min(args.steps, 4))
-    n_stream = args.warmup + args.steps + 1
+    n_stream = (args.warmup + args.steps + 1) * uf
     per_tree_img = int(round(args.image_frac * args.nodes))
     rng_pool = np.random.Generator(np.random.PCG64(99 + rank))
     pool = rng_pool.standard_normal((max(per_tree_img * 6, 1) + 64, 3, cfg["image"], cfg["image"]), dtype=np.float32) if per_tree_img else None
@@ -602,19 +620,33 @@ def main():
         del check_batch
 
     def step(pb, marks=None):
+        """one step = ``uf`` micro-batches (a list when uf > 1) accumulated into the gradient arena, then the exchange (+ Adam)"""
         mark = (lambda name: marks.append((name, time.perf_counter()))) if marks is not None else (lambda name: None)
         mark("start")
         dp.zero_grad()
-        sample = {"nsamples": pb.B, "net_input": {"batched_data": pb.batched_data}}
         mark("zero_grad")
-        loss, sample_size, log = crit(model, sample)
-        mark("forward+loss")
-        loss.backward()
-        mark("backward")
-        scal[0] = loss.detach().float()
-        scal[1].fill_(float(sample_size))        # (scal[1] = <python float> is a synchronous H2D copy: tools/sync_probe.py)
-        scal[2:6] = torch.stack([log["ncorrect"], log["num_positive_correct"], log["total_positive"],
-                                 log["num_pred_positive"]]).float()
+        if uf == 1:
+            sample = {"nsamples": pb.B, "net_input": {"batched_data": pb.batched_data}}
+            loss, sample_size, log = crit(model, sample)
+            mark("forward+loss")
+            loss.backward()
+            mark("backward")
+            scal[0] = loss.detach().float()
+            scal[1].fill_(float(sample_size))        # (scal[1] = <python float> is a synchronous H2D copy: tools/sync_probe.py)
+            scal[2:6] = torch.stack([log["ncorrect"], log["num_positive_correct"], log["total_positive"],
+                                     log["num_pred_positive"]]).float()
+        else:
+            scal.zero_()
+            for k, micro in enumerate(pb):
+                dp.accumulate(k == uf - 1)           # buckets leave with the LAST micro-batch's backward (train.py does the same)
+                loss, sample_size, log = crit(model, {"nsamples": micro.B, "net_input": {"batched_data": micro.batched_data}})
+                loss.backward()
+                scal[0] += loss.detach().float()
+                scal[1] += float(sample_size)
+                scal[2:6] += torch.stack([log["ncorrect"], log["num_positive_correct"], log["total_positive"],
+                                          log["num_pred_positive"]]).float()
+            mark("forward+loss")
+            mark("backward")
         mark("scalars")
         gscale = dp.finish_backward(scal, fold_scale=opt is not None)     # 1 / sample size rides on Adam's read of the gradients
         if opt is not None:
@@ -633,6 +665,14 @@ def main():
     else:
         pf = Prefetcher(iter(host_trees), lambda ts: pack_batch(ts, spatial_pos_max=5), depth=2, warm=warm_indices)
         batches = pf
+    if uf > 1:
+        single = batches
+
+        def grouped():
+            while True:
+                yield [next(single) for _ in range(uf)]
+        batches = grouped()
+    n_comments = (lambda b: sum(m.M for m in b)) if uf > 1 else (lambda b: b.M)
     comments = []
     for i in range(args.warmup):
         step(next(batches))
@@ -642,7 +682,7 @@ def main():
     ev[0].record()
     for i in range(args.steps):
         pb = next(batches)
-        comments.append(pb.M)
+        comments.append(n_comments(pb))
         step(pb)
         ev[i + 1].record()
     fence()
@@ -668,7 +708,7 @@ def main():
     if not args.no_gemm_timer:
         two = ge_.two_streams
         ge_.two_streams = False
-        roof = [last, pack_batch(host_trees[0], spatial_pos_max=5)]
+        roof = [last, pack_batch(host_trees[0], spatial_pos_max=5) if uf == 1 else [pack_batch(host_trees[k], spatial_pos_max=5) for k in range(uf)]]
         for pb in roof:             # untimed: the one-stream layout takes its blocks from the main stream's pool for the first time
             step(pb)
         timer.enabled = True
@@ -727,8 +767,14 @@ def main():
         fkw = dict(Lb=cfg["layers"] - Lf, Lf=Lf, G=Lf, N=args.nodes, rho=args.image_frac, D=cfg["dim"], F=cfg["ffn"], Fg=cfg["dim"],
                    P=(cfg["image"] // cfg["patch"]) ** 2 + 1, patch=cfg["patch"])
         pruned = bool(ge_.prune_last_layer)
-        fpc = flops_per_comment(lens=tok_lens if ragged else None, prune_last=pruned, **fkw)   # FLOPs this implementation executes
-        fpc_padded = flops_per_comment(**fkw)                                  # FLOPs of the reference's padded layout
+        G_exec = Lf if cfg.get("fusion_stack", 1) == 1 else -(-Lf // cfg["fusion_stack"]) * cfg.get("graph_stack", 1)   # one graph stack per fusion stack runs (the last of the list never does)
+        fkw["G"] = G_exec
+        frozen = bool(args.freeze_initial_encoders)
+        # FLOPs this implementation executes / FLOPs of the reference's padded layout: per comment, forward + backward (3 x forward;
+        # a frozen prefix counted once)
+        fpc3 = flops_per_comment(lens=tok_lens if ragged else None, prune_last=pruned, frozen_prefix=True, **fkw) if frozen else \
+            3 * flops_per_comment(lens=tok_lens if ragged else None, prune_last=pruned, **fkw)
+        fpc3_padded = flops_per_comment(frozen_prefix=True, **fkw) if frozen else 3 * flops_per_comment(**fkw)
         gs = timer.summary()
         if os.environ.get("MDT_BENCH_GEMM_TABLE") == "1" and gs:
             print(timer.table(), file=sys.stderr, flush=True)
@@ -773,14 +819,16 @@ def main():
                                    + ("last fusion layer computes only the rows read afterwards, " if pruned else "")
                                    + ("every step packs, uploads and indexes a batch it has not seen (prefetch thread, copy stream), "
                                       if pf is not None else "two pre-packed HBM-resident batches alternate, ")
+                                   + (f"a step = one update of {uf} micro-batches (--update-freq {uf}), " if uf > 1 else "")
+                                   + ("frozen pre-fusion encoders (no adjoint, counted once in the FLOPs), " if frozen else "")
                                    + ("fused Adam step included" if opt is not None else "no optimizer step (metric: fwd+bwd)"),
                        "name": args.config, "trees_per_gpu": args.trees, "comments_per_step_per_gpu": round(n_com, 1),
                        "parallelism": f"dp{world}", "frozen_initial_encoders": bool(args.freeze_initial_encoders)},
             "ms_per_step_median": round(ms_median, 2),
             "packer_h2d_ms": packer_ms, "packer_host_ms": packer_host_ms, "tree_generation_s_untimed": round(t_gen, 2),
-            "model_tflops": round(value * 3 * fpc / 1e12, 1),
-            "model_frac_of_bf16_peak": round(value * 3 * fpc / 1e12 / (BF16_DENSE_PEAK_TFLOPS * world), 4),
-            "padded_equivalent_tflops": round(value * 3 * fpc_padded / 1e12, 1),
+            "model_tflops": round(value * fpc3 / 1e12, 1),
+            "model_frac_of_bf16_peak": round(value * fpc3 / 1e12 / (BF16_DENSE_PEAK_TFLOPS * world), 4),
+            "padded_equivalent_tflops": round(value * fpc3_padded / 1e12, 1),
             "text_layout": "ragged" if ragged else "padded",
             "compute_streams": 2 if ge_.two_streams else 1,     # image branch beside the text branch
             "host_issue_ms_per_step": round(t_issue * 1e3, 2), "host_issue_phases_ms": host_phases,

@@ -84,6 +84,12 @@ def real_hparams(kind):
         return R.hparams(dim=128, enc_heads=2, graph_heads=8, enc_ffn=512, graph_ffn=128, text_layers=4,
                          vit_layers=4, num_fusion_layers=1, num_fusion_stack=1, num_graph_stack=1, num_bottleneck=4,
                          vocab_size=30522, max_pos=512, image_size=32, patch=16, pos_weight=1.5, neg_weight=1.0)
+    if kind == "LAUNCH":  # the configuration the reference SHIPS: sample_run.sh:3 = `run_train.sh 8 4 5 2 2 0` — 8 fusion layers
+        # (BERT-base / ViT-B/16 split 3 + 9), 4 bottleneck tokens, spatial_pos_max 5, graph stacks of 2 (10 executed graph layers),
+        # fusion stacks of 2 (uneven last stack: 9 = 2+2+2+2+1), graph FFN 768 (run_train.sh:57), --freeze_initial_encoders (:61)
+        return R.hparams(dim=768, enc_heads=12, graph_heads=12, enc_ffn=3072, graph_ffn=768, text_layers=12, vit_layers=12,
+                         num_fusion_layers=8, num_fusion_stack=2, num_graph_stack=2, num_bottleneck=4, vocab_size=30522,
+                         max_pos=512, image_size=224, patch=16, pos_weight=1.5, neg_weight=1.0, freeze_initial_encoders=True)
     if kind == "M":
         return tiny_hparams("A")
     raise KeyError(kind)
@@ -120,6 +126,11 @@ def real_trees(kind, hp):
         trees = [synthetic.make_tree(16, rng, seq_len=100, vocab_size=hp.vocab_size, image_frac=0.0,
                                      image_size=hp.image_size, shape="bushy", min_len=8) for _ in range(8)]
         return _label_many(trees, every=2)
+    if kind == "LAUNCH":  # two trees of the launch's 12-tree batch (what the CPU reference runs in about a minute): L = 100, 224-px images
+        rng = np.random.Generator(np.random.PCG64(8452))
+        trees = [synthetic.make_tree(n, rng, seq_len=100, vocab_size=hp.vocab_size, image_frac=f, image_size=hp.image_size,
+                                     shape=s, min_len=8) for n, f, s in ((13, 0.25, "bushy"), (9, 0.34, "deep"))]
+        return _label_many(trees, every=1)
     if kind == "M":
         rng = np.random.Generator(np.random.PCG64(515))
         spec = ((8, 0.25, "bushy"), (7, 0.0, "deep"), (5, 0.4, "bushy"), (4, 0.0, "deep"))
@@ -132,7 +143,7 @@ def real_trees(kind, hp):
 # node_classifier.bias per case: minus / plus half the median logit margin of the hash-weight model (measured once with
 # the oracle, tools/margin_probe.py), so that about half of the comments are predicted positive.  Applied identically
 # to the reference (gen_golden), the oracle (make_weights) and the product (tests.util_model.fill_hash_weights).
-_BIAS_SHIFT = {"C2": 0.68, "C4": 0.0874, "M": 1.0912, "C1": -0.2122039}   # C1: the midpoint of the widest gap (1.3e-3) between the sorted zero-bias margins around their median: no labelled comment within 6e-4 of a tie
+_BIAS_SHIFT = {"C2": 0.68, "C4": 0.0874, "M": 1.0912, "C1": -0.2122039, "LAUNCH": 0.229}   # C1: the midpoint of the widest gap (1.3e-3) between the sorted zero-bias margins around their median: no labelled comment within 6e-4 of a tie
 
 
 def weight_overrides(kind):

@@ -251,7 +251,7 @@ def build_reference_encoder(mods, hp):
         embedding_dim=hp.dim, ffn_embedding_dim=hp.graph_ffn, num_attention_heads=hp.graph_heads,
         dropout=0.0, attention_dropout=0.0, activation_dropout=0.0,
         encoder_normalize_before=hp.encoder_normalize_before, pre_layernorm=hp.pre_layernorm,
-        activation_fn="gelu",
+        activation_fn="gelu", freeze_initial_encoders=bool(getattr(hp, "freeze_initial_encoders", False)),
     )
     return enc
 
@@ -433,7 +433,7 @@ def case_full_model(mods, models, collator_mod, pre, updown, loss_mod, metrics, 
         else:       # "M": tiny shapes, mixed predictions; "C2": BASELINE.json configs[1] at its true geometry
             hp, over = cases.real_hparams(kind), cases.weight_overrides(kind)
             trees = cases.real_trees(kind, hp)
-            fname = {"M": "full_tiny768_M.npz", "C2": "full_c2_real.npz"}[kind]
+            fname = {"M": "full_tiny768_M.npz", "C2": "full_c2_real.npz", "LAUNCH": "full_launch.npz"}[kind]
         items = ref_items_from_trees(trees, pre, updown)
         batch = ref_collate(items, collator_mod, 5)
         enc = build_reference_encoder(mods, hp)

@@ -147,8 +147,17 @@ def make_weights(hp, dtype=torch.float32, requires_grad=True, overrides=None) ->
             t = torch.from_numpy(overrides[name].reshape(shape).copy()).to(dtype)
         else:
             t = torch.from_numpy(hashinit.param(name, shape)).to(dtype)
-        W[name] = t.requires_grad_(requires_grad)
+        W[name] = t.requires_grad_(requires_grad and not is_frozen(hp, name))
     return W
+
+
+def is_frozen(hp, name: str) -> bool:
+    """--freeze_initial_encoders (multigraphormer_graph_encoder.py:223-228): every parameter of text_model and vit_model —
+    embeddings, the pre-fusion layers left there after the fusion layers were sliced out, the ViT's final LayerNorm —
+    except the two poolers, which are unfrozen again."""
+    if not getattr(hp, "freeze_initial_encoders", False):
+        return False
+    return (name.startswith("text_model.") or name.startswith("vit_model.")) and ".pooler." not in name
 
 
 # --------------------------------------------------------------------------- blocks

@@ -164,17 +164,19 @@ def full_case(kind):
         hp = cases.tiny_hparams(kind)
         return f"full_tiny768_{kind}.npz", hp, cases.tiny_trees(kind, hp), {}
     hp = cases.real_hparams(kind)
-    fname = {"M": "full_tiny768_M.npz", "C2": "full_c2_real.npz"}.get(kind)        # C4, C4F, C1: the reference cannot run D != 768
+    fname = {"M": "full_tiny768_M.npz", "C2": "full_c2_real.npz", "LAUNCH": "full_launch.npz"}.get(kind)        # C4, C4F, C1: the reference cannot run D != 768
     return fname, hp, cases.real_trees(kind, hp), cases.weight_overrides(kind)
 
 
-@pytest.mark.parametrize("kind", ["A", "B", "M", "C2"])
+@pytest.mark.parametrize("kind", ["A", "B", "M", "C2", "LAUNCH"])
 def test_full_model(golden_dir, kind):
     """The oracle against the REAL reference's outputs.  "M": mixed predictions (TP, FP, FN all non-zero);
-    "C2": BASELINE.json configs[1] at its true geometry (L 100, 224-px images, FFN 3072, 6 + 6 layers, 64-comment tree)."""
+    "C2": BASELINE.json configs[1] at its true geometry (L 100, 224-px images, FFN 3072, 6 + 6 layers, 64-comment tree);
+    "LAUNCH": the configuration the reference ships (sample_run.sh:3 = 8 4 5 2 2 0: split 3 + 9, fusion and graph stacks of 2,
+    graph FFN 768, --freeze_initial_encoders: the frozen prefix gets no gradient), two trees of its batch."""
     fname, hp, trees, over = full_case(kind)
     g = _load(golden_dir, fname)
-    if kind in ("M", "C2"):
+    if kind in ("M", "C2", "LAUNCH"):
         tp, predp, totp = int(g["log/num_positive_correct"]), int(g["log/num_pred_positive"]), int(g["log/total_positive"])
         assert tp > 0 and predp > tp and totp > tp and int(g["log/ncorrect"]) > tp      # TP, FP, FN, TN all present
     batch = R.to_torch_batch(S.collate(trees, 5))

@@ -16,6 +16,10 @@
         one 128-comment deep thread: what depth compounding at D = 1024 does to the bf16 path, measured once against the
         fp32 oracle on the same bf16-rounded weights (a ~2-minute CPU pass).
   "M"   tiny shapes, mixed predictions (TP / FP / FN / TN all non-zero).
+  "LAUNCH" the configuration the reference SHIPS (sample_run.sh:3 = `run_train.sh 8 4 5 2 2 0`, run_train.sh:41-65): BERT-base +
+        ViT-B/16 split 3 + 9, fusion stacks of 2 (uneven last stack), graph stacks of 2 (10 executed graph layers), graph FFN
+        768, --freeze_initial_encoders (the frozen prefix gets no gradient and its adjoint never runs), two trees of the
+        launch's 12-tree batch at L = 100 / 224 px.  Checked against the REAL reference (tests/golden/full_launch.npz).
 
 fp32: north_star's 1e-3 gate on logits and on EVERY parameter gradient, both text layouts; counters / F1 exact.
 bf16: logits within 0.05, every parameter gradient within a relative L2 of BF16_GRAD_REL_L2 of the fp32 oracle run on
@@ -84,7 +88,7 @@ def product_run(kind, dtype, ragged, main_grad=False):
 
 
 @pytest.mark.parametrize("ragged", [False, True], ids=["padded", "ragged"])
-@pytest.mark.parametrize("kind", ["M", "C1", "C2", "C4"])
+@pytest.mark.parametrize("kind", ["M", "C1", "C2", "C4", "LAUNCH"])
 def test_fp32_real_shapes_vs_reference_golden_and_oracle(golden_dir, kind, ragged):
     from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
     o = oracle_run(kind, rounded=False)
@@ -145,7 +149,7 @@ def test_fp32_real_shapes_vs_reference_golden_and_oracle(golden_dir, kind, ragge
           f"{n} parameter gradients, worst {worst[1]:.2e} ({worst[0]})")
 
 
-@pytest.mark.parametrize("kind", ["M", "C2", "C4"])
+@pytest.mark.parametrize("kind", ["M", "C2", "C4", "LAUNCH"])
 def test_bf16_real_shapes_vs_fp32_oracle(kind):
     """The production dtype at the real shapes: bf16 MFMA GEMMs / attention, fp32 softmax, LayerNorm statistics and
     gradient arena, ragged text, against the fp32 oracle on the same bf16-rounded weights.  Every parameter gradient is

@@ -17,7 +17,7 @@ def model_args(hp, **over):
         encoder_embed_dim=hp.dim, encoder_ffn_embed_dim=hp.graph_ffn, encoder_attention_heads=hp.graph_heads,
         dropout=0.0, attention_dropout=0.0, act_dropout=0.0, encoder_normalize_before=hp.encoder_normalize_before,
         pre_layernorm=hp.pre_layernorm, apply_graphormer_init=False, activation_fn="gelu",
-        freeze_initial_encoders=False, share_encoder_input_output_embed=False, max_nodes=512, num_classes=1,
+        freeze_initial_encoders=bool(getattr(hp, "freeze_initial_encoders", False)), share_encoder_input_output_embed=False, max_nodes=512, num_classes=1,
         bert_config=dict(dim=hp.dim, layers=hp.text_layers, heads=hp.enc_heads, intermediate=hp.enc_ffn,
                          vocab=hp.vocab_size, max_pos=hp.max_pos, type_vocab=hp.type_vocab),
         vit_config=dict(dim=hp.dim, layers=hp.vit_layers, heads=hp.enc_heads, intermediate=hp.enc_ffn,
