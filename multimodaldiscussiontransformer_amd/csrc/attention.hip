@@ -612,11 +612,10 @@ static int dispatch(hipStream_t st, const AttnParams& p) {
       const char* force = switches().attn_bwd[0] ? switches().attn_bwd : nullptr;      // MDT_ATTN_BWD = "v1" | "v2" | "v3" for A/B runs
       const bool drop = a.drop_p > 0.f;                // with dropout the whole-row v2 falls to 1 wave / SIMD: chunked v3 wins
       if (BWD && a.S > 256 && !force) return attention_v3_bwd_dispatch(st, p);   // ViT-L/14: 4 + 257 tokens
-      // (round 3: sending plain rows of up to 80 tokens to the one-pass v4 instead is 3 x faster — 749 -> 225 us on 2048 ragged
-      // sequences of 10-64 tokens — but v4 forms delta = rowsum(dO o O) from the bf16 output where this kernel sums P o dP in
-      // fp32, and on the C4F fixture (query / key gradients at 1e-3 of the block's gradient scale) that noise is 1.8 of the
-      // remnant: the routing stays until v4 forms delta itself)
-      const bool v1 = force ? !strcmp(force, "v1") : a.S <= 80;
+      // (plain rows of up to 80 tokens take the one-pass kernel since round 4 — 3 x faster, 749 -> 225 us on 2048 ragged sequences
+      // of 10-64 tokens — now that its short-row form sums delta = sum P o dP itself, in fp32, like the scratch kernel does
+      // (attn_bwd_v4x); graphs with a structural bias stay here)
+      const bool v1 = force ? !strcmp(force, "v1") : (a.S <= 80 && (st_bias || !switches().attn_exact_delta));
       // the whole-row v2 backward knows nothing of q_limit (rows the forward skipped have no lse): those launches take v3 / v4
       const bool v2 = (force ? !strcmp(force, "v2") : (!drop && a.q_limit == 0)) && a.S <= 112;
       if (!v1) return v2 ? attention_v2_dispatch(st, p, true) : attention_v3_bwd_dispatch(st, p);

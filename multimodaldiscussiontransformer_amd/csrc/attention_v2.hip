@@ -817,8 +817,17 @@ __device__ __forceinline__ bf16x8 v2_frag_tr_ld(const bf16_t* img, int ld, int t
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int HD, bool DROP>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_v4_kernel(AttnParams P, int rows_img, int ldq) {
+// EXACT (rows of at most 6 tiles = 96 tokens, launch_v3): delta_i = sum_j P_ij dP_ij is formed HERE, in fp32, from the very P and dP
+// that make dS — not as rowsum(dO o O) from the forward's bf16-rounded output.  The two are equal in exact arithmetic; with O
+// rounded to 2^-9 the second one is off by dO . (O_bf16 - O), the same for every key of a row, which is harmless at the block's
+// gradient scale but is what is LEFT of the query / key gradients where the softmax is nearly uniform (C4F fixture: |g_query| at
+// 1e-3 ... 1e-5 of |g_value|, tests/test_real_shapes_gpu.py).  A wave owns one key tile and at most three query-tile pairs, so
+// phase 1 runs as two sweeps with P and dP of all its pairs held in registers (48): sweep A forms them, sums p * dP over the
+// wave's 16 keys (four DPP row rotations) and adds the row sums to the delta image in LDS (ds_add_f32, one lane per row group);
+// behind a workgroup barrier sweep B forms dS with the finished delta.  The output of the forward is not read at all.
+constexpr int V4_EXACT_PAIRS = 3;
+template <int HD, bool DROP, bool EXACT>
+__device__ __forceinline__ void attn_bwd_v4_body(const AttnParams& P, int rows_img, int ldq) {
   constexpr int ND = HD / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mdt_attn_fwd_args& a = P.f;
@@ -870,7 +879,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
       const int rc = r < S ? r : S - 1, ro = r < q_rows ? r : q_rows - 1;
       cq[j] = *(const bf16x8*)(qkv + rc * tld + c8 * 8);
       cg[j] = *(const bf16x8*)(dout + rc * dld + c8 * 8);
-      co[j] = *(const bf16x8*)(outp + ro * old_ + c8 * 8);
+      if constexpr (!EXACT) co[j] = *(const bf16x8*)(outp + ro * old_ + c8 * 8);
+      else co[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};       // delta starts at zero: phase 1 sums it
     }
     const int ti = tid < rows_live ? tid : 0;
     const float lv = a.lse[((int64_t)seq * a.H + h) * SL + (ti < q_rows ? ti : q_rows - 1)];
@@ -918,7 +928,88 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     f32x4 dv[ND], dk[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) { dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    for (int pr = 0; pr < n_pair_q; ++pr) {
+    if constexpr (EXACT) {
+      // ---- sweep A: P and dP of every pair (registers), delta += row sums of p * dP over this wave's keys
+      f32x4 pA[V4_EXACT_PAIRS][2], dA[V4_EXACT_PAIRS][2];
+      unsigned keepA[V4_EXACT_PAIRS];
+#pragma unroll
+      for (int pr = 0; pr < V4_EXACT_PAIRS; ++pr) {
+        keepA[pr] = 0xFFu;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { pA[pr][t] = f32x4{0.f, 0.f, 0.f, 0.f}; dA[pr][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (pr < n_pair_q) {
+          const int t0 = 2 * pr;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) {
+              pA[pr][t] = mfma_bf16(v2_frag_lds(img0, (t0 + t) * 16, ks * 32, lane), fk[ks], pA[pr][t]);   // S[q][key]
+              dA[pr][t] = mfma_bf16(v2_frag_lds(img1, (t0 + t) * 16, ks * 32, lane), fv[ks], dA[pr][t]);   // dP[q][key]
+            }
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int qb = (t0 + t) * 16 + 4 * g;
+            const f32x4 l2v = *(const f32x4*)(s_lse + qb);
+            bool keep[4] = {true, true, true, true};
+            if constexpr (DROP) {
+              const uint32_t ra = kh + (uint32_t)(qb + 2 * odd) * s2h;
+              const uint32_t wa = drop_mix(ra ^ P.drop.key), wb = drop_mix((ra + s2h) ^ P.drop.key);
+              const uint32_t pa = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wa, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+              const uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wb, 0xB1, 0xF, 0xF, false);
+              const uint32_t w[4] = {odd ? pa : wa, odd ? pb : wb, odd ? wa : pa, odd ? wb : pb};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                keep[r] = ((w[r] >> (16 * odd)) & 0xFFFFu) >= P.drop.thresh;
+                if (!keep[r]) keepA[pr] &= ~(1u << (4 * t + r));
+              }
+            }
+            float x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = __builtin_fmaf(pA[pr][t][r], scale2, kb);
+              const float p = __builtin_amdgcn_exp2f(v - l2v[r]);
+              const float dpv = keep[r] ? dA[pr][t][r] : 0.f;
+              pA[pr][t][r] = p;
+              dA[pr][t][r] = dpv;
+              x[r] = row16_sum_dpp(p * dpv);          // over the 16 keys of this tile: every lane of the row group holds it
+            }
+            if (c == 0) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) atomicAdd(s_delta + qb + r, x[r]);      // ds_add_f32: the key tiles of the other waves add theirs
+            }
+          }
+        }
+      }
+      __syncthreads();                             // every wave's row sums are in the delta image (the waves without a key tile meet this barrier below)
+      // ---- sweep B: dS = p (dP - delta) with the finished delta; products as in the one-sweep form
+#pragma unroll
+      for (int pr = 0; pr < V4_EXACT_PAIRS; ++pr) {
+        if (pr < n_pair_q) {
+          const int t0 = 2 * pr;
+          f32x4 sc[2], dp[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const f32x4 dlv = *(const f32x4*)(s_delta + (t0 + t) * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float p = pA[pr][t][r];
+              dp[t][r] = p * (dA[pr][t][r] - dlv[r]);
+              sc[t][r] = (keepA[pr] >> (4 * t + r)) & 1u ? p : 0.f;
+            }
+          }
+          const bf16x8 fp = v2_pack(sc[0], sc[1]);
+          const bf16x8 fs = v2_pack(dp[0], dp[1]);
+          *(bf16x4*)(ds_row + t0 * 16) = bf16x4{fs[0], fs[1], fs[2], fs[3]};
+          if (t0 + 1 < n_tq) *(bf16x4*)(ds_row + t0 * 16 + 16) = bf16x4{fs[4], fs[5], fs[6], fs[7]};
+#pragma unroll
+          for (int d = 0; d < ND; ++d) {
+            dv[d] = mfma_bf16(v2_frag_tr(img1, t0, d * 16, lane), fp, dv[d]);
+            dk[d] = mfma_bf16(v2_frag_tr(img0, t0, d * 16, lane), fs, dk[d]);
+          }
+        }
+      }
+    }
+    for (int pr = 0; pr < (EXACT ? 0 : n_pair_q); ++pr) {
       const int t0 = 2 * pr;
       f32x4 sc[2], dp[2];
 #pragma unroll
@@ -977,6 +1068,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
       *(bf16x8*)vrow = vv.a;
       *(bf16x8*)(vrow + 32) = vv.b;
     }
+  } else if constexpr (EXACT) {
+    __syncthreads();                               // the delta barrier between the two sweeps of the waves that own a key tile
   }
   // K goes where Q was — from the registers that already hold it: the K fragments of the waves ARE the rows of K (lane
   // (g, c) of the owner of key tile kt holds chunks g and 4 + g of row 16 kt + c), so K is read from memory once per
@@ -1006,6 +1099,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
       *(bf16x8*)(orow + 32) = qv.b;
     }
   }
+}
+
+template <int HD, bool DROP>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_v4_kernel(AttnParams P, int rows_img, int ldq) {
+  attn_bwd_v4_body<HD, DROP, false>(P, rows_img, ldq);
+}
+// rows of at most 96 tokens: 4 or 8 waves per workgroup, P / dP of three query-tile pairs in registers (no 128-register cap)
+template <int HD, bool DROP>
+__global__ __launch_bounds__(512) void attn_bwd_v4x_kernel(AttnParams P, int rows_img, int ldq) {
+  attn_bwd_v4_body<HD, DROP, true>(P, rows_img, ldq);
 }
 
 // ---------------------------------------------------------------------------- one-pass backward, persistent (v5)
@@ -1387,6 +1490,21 @@ static int launch_v3(hipStream_t st, const AttnParams& p) {
       if (rows_img * 8 > 2 * waves * 64 || n_t > waves) {      // two 16-byte chunks per thread and image, one key tile per wave
         set_error("attention_bwd_v4: %d image rows for %d waves", rows_img, waves);
         return MDT_ERR_UNSUPPORTED;
+      }
+      // rows of at most 96 tokens (three query-tile pairs): delta summed in the kernel from P and dP (MDT_ATTN_EXACT_DELTA=0: from the bf16 output)
+      if (n_t <= 2 * V4_EXACT_PAIRS && switches().attn_exact_delta) {
+        auto k4x = attn_bwd_v4x_kernel<64, DROP>;
+        static bool attr_x = false;
+        if (!attr_x) {
+          if (hipFuncSetAttribute((const void*)k4x, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("attention_bwd_v4x: cannot reserve 160 KiB of LDS");
+            return MDT_ERR_LAUNCH;
+          }
+          attr_x = true;
+        }
+        hipLaunchKernelGGL(k4x, dim3(p.f.H, p.f.nseq), waves * 64, lds4, st, p, rows_img, ldq);
+        return check_launch("attention_bwd_v4x");
       }
       hipLaunchKernelGGL(k4, dim3(p.f.H, p.f.nseq), waves * 64, lds4, st, p, rows_img, ldq);
       return check_launch("attention_bwd_v4");

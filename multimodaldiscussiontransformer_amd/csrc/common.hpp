@@ -54,6 +54,7 @@ struct Switches {
   char attn_bwd[8];          // MDT_ATTN_BWD       ("" unset)
   bool attn_no_occ4;         // MDT_ATTN_NO_OCC4
   bool attn_no_w8;           // MDT_ATTN_NO_W8
+  bool attn_exact_delta;     // MDT_ATTN_EXACT_DELTA (default 1: one-pass backward of rows <= 96 tokens sums delta = sum P o dP itself; 0: rowsum(dO o O) from the bf16 output)
   int attn_onepass;          // MDT_ATTN_ONEPASS   (0: two-pass backward kernels only; default: one-pass wherever its dS image fits LDS)
 };
 const Switches& switches();

@@ -48,6 +48,7 @@ static void read_switches() {
   g_sw.gemm_group = num("MDT_GEMM_GROUP", -1);
   g_sw.gemm_stamp = flag("MDT_GEMM_STAMP");
   g_sw.gemm_no_spec = flag("MDT_GEMM_NO_SPEC");
+  g_sw.attn_exact_delta = num("MDT_ATTN_EXACT_DELTA", 1) != 0;
   g_sw.gemm_diag = num("MDT_GEMM_DIAG", 0);
   str("MDT_GEMM_TILE", g_sw.gemm_tile, sizeof(g_sw.gemm_tile));
   g_sw.gemm_no_pp = flag("MDT_GEMM_NO_PP");

@@ -57,6 +57,9 @@ def build_parser():
     p.add_argument("--max-update", type=int, default=0)
     p.add_argument("--fp16", action="store_true", default=False, help="the reference's half precision; runs as bf16 here")
     p.add_argument("--bf16", action="store_true", default=False)
+    p.add_argument("--fp8", action="store_true", default=False,
+                   help="BASELINE.json configs[4] (not a reference flag): bf16 run with per-tensor-scaled fp8 operands in the blocks' big GEMMs (fp8.py)")
+    p.add_argument("--fp8-sites", default=None, help="preset (all | fast4 | grads) or comma list of fp8 sites (fp8.PRESETS); default all")
     p.add_argument("--log-interval", type=int, default=10)
     # criterion flags: every field of every registered criterion's config dataclass (FairSeq derives them the same way)
     from .registry import CRITERION_REGISTRY as _CR
@@ -167,10 +170,11 @@ def main(argv=None):
         raise SystemExit(f"[mdt-train] {e}\n[mdt-train] give --pretrained-bert / --pretrained-vit a local path, start from a "
                          f"checkpoint (--restore-file), or pass --random-init-encoders to train from random weights")
     model = model.cuda()
-    half = args.fp16 or args.bf16
+    half = args.fp16 or args.bf16 or args.fp8
     if half:
         model = model.bfloat16()
     model.train()
+    fp8_state = model.enable_fp8(sites=args.fp8_sites) if args.fp8 else None      # the optimiser tells it when the weight copies go stale
     dp = DataParallel(model)
     dp.broadcast_parameters()
     crit_cls, _ = CRITERION_REGISTRY[args.criterion]
@@ -359,7 +363,10 @@ def main(argv=None):
         save(args.save_checkpoint, max_update)
     if rank == 0 and args.save_dir and not args.no_save:
         save(os.path.join(args.save_dir, "checkpoint_last.pt"), max_update)
-    main.last_run = dict(model=model, criterion=crit, valid_batches=valid_batches, optimizer=opt)     # for tests / notebooks
+    main.last_run = dict(model=model, criterion=crit, valid_batches=valid_batches, optimizer=opt, fp8=fp8_state)     # for tests / notebooks
+    if fp8_state is not None:
+        from . import fp8 as _fp8
+        _fp8.ACTIVE = None                           # process-wide switch: a later model in this process starts in bf16
     if world > 1:
         dist.destroy_process_group()
     return history
