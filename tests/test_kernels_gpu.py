@@ -738,7 +738,9 @@ def test_attention_backward_one_pass_equals_two_pass(ops, S, ragged, qlim, p, mo
     assert torch.isfinite(grads[1]).all()
     scale = grads[0].abs().max().item()
     assert (grads[0] - grads[1]).abs().max().item() <= 8e-3 * max(scale, 1.0)
-    assert ((grads[0] - grads[1]).norm() / grads[0].norm()).item() <= 1e-3
+    # rows of at most 96 tokens: the one-pass kernel sums delta = sum P o dP itself (attn_bwd_v4x) where the two-pass kernels take
+    # rowsum(dO o O) from the bf16 output — the two differ by that rounding (dedicated test below)
+    assert ((grads[0] - grads[1]).norm() / grads[0].norm()).item() <= (3e-3 if S <= 96 else 1e-3)
 
 
 # ----------------------------------------------------------------------------- persistent one-pass backward (long rows)
@@ -931,8 +933,8 @@ def test_attention_beyond_272_tokens_key_chunked_path(ops, dtype, S, struct, p):
 # ----------------------------------------------------------------------------- delta = sum P o dP formed in the one-pass backward (short rows)
 @pytest.mark.parametrize("S,ragged,p", [(52, False, 0.0), (80, True, 0.0), (96, False, 0.3), (33, True, 0.1)])
 def test_attention_backward_short_rows_sum_delta_themselves(ops, S, ragged, p, monkeypatch):
-    """VERDICT r3 item 6.  With a nearly uniform softmax (query / key projections at 2 % of the value scale — the deep pre-fusion
-    blocks of the C4F fixture) the query / key gradients are what is left after dP - delta almost cancels, and
+    """VERDICT r3 item 6.  Where the value rows of a sequence are nearly equal (the deep pre-fusion blocks of the C4F fixture) the
+    query / key gradients are what is left after dP - delta almost cancels, and
     delta = rowsum(dO o O) taken from the forward's bf16-rounded O is off by dO . (O_bf16 - O): the same offset for every key of a
     row, a large fraction of that remnant.  attn_bwd_v4x (rows <= 96 tokens) sums delta = sum_j P_ij dP_ij itself in fp32: dQ / dK
     must sit within 2 % (relative L2) of an fp64 computation on the same bf16 inputs and masks, and the old form
@@ -950,7 +952,10 @@ def test_attention_backward_short_rows_sum_delta_themselves(ops, S, ragged, p, m
     off[1:] = torch.cumsum(lens, 0)
     rows = int(off[-1])
     qkv = torch.randn(rows, 3 * D, generator=g)
-    qkv[:, :2 * D] *= 0.02                                   # q, k tiny: scores ~ 1e-3, softmax ~ uniform
+    qkv[:, :2 * D] *= 0.5
+    # value rows that differ by 3 % around a common vector (representation collapse of the deep blocks): dP_ij = dO_i . V_j is then
+    # nearly the same for every key j and dP - delta is what is left of it
+    qkv[:, 2 * D:] = torch.randn(1, D, generator=g) + 0.03 * qkv[:, 2 * D:]
     qkv = qkv.to(torch.bfloat16)
     dout = torch.randn(rows, D, generator=g).to(torch.bfloat16)
     kw = dict(drop_p=p, drop_seed=77)
@@ -976,6 +981,7 @@ def test_attention_backward_short_rows_sum_delta_themselves(ops, S, ragged, p, m
         ref[r0:r0 + n] = x.grad
     res = {}
     try:
+        monkeypatch.setenv("MDT_ATTN_BWD", "v3")             # the route of the length-binned production launches: one-pass kernels
         for exact in ("1", "0"):
             monkeypatch.setenv("MDT_ATTN_EXACT_DELTA", exact)
             L.reload_env()
@@ -984,7 +990,11 @@ def test_attention_backward_short_rows_sum_delta_themselves(ops, S, ragged, p, m
             res[exact] = [float((d[:, i * D:(i + 1) * D] - ref[:, i * D:(i + 1) * D]).norm() / ref[:, i * D:(i + 1) * D].norm()) for i in range(3)]
     finally:
         monkeypatch.delenv("MDT_ATTN_EXACT_DELTA")
+        monkeypatch.delenv("MDT_ATTN_BWD")
         L.reload_env()
     print(f"[S {S} ragged {ragged} p {p}] rel-L2 of dQ / dK / dV: delta summed in the kernel {res['1']}, from the bf16 output {res['0']}")
     assert res["1"][0] < 2e-2 and res["1"][1] < 2e-2 and res["1"][2] < 1e-2, res
-    assert res["0"][0] > 2 * res["1"][0] and res["0"][1] > 2 * res["1"][1], res
+    if p == 0:     # (dropout decorrelates dP along a row: the remnant is no longer small there, either form is at the bf16 floor)
+        assert res["0"][0] > 10 * res["1"][0] and res["0"][1] > 10 * res["1"][1], res
+    else:
+        assert res["0"][0] >= res["1"][0] and res["0"][1] >= res["1"][1], res

@@ -53,7 +53,7 @@ def oracle_run(kind, rounded: bool):
         fname, hp, trees, over = full_case(kind)
         W = R.make_weights(hp, overrides=over)
         if rounded:
-            W = {n: w.detach().bfloat16().float().requires_grad_(True) for n, w in W.items()}
+            W = {n: w.detach().bfloat16().float().requires_grad_(not R.is_frozen(hp, n)) for n, w in W.items()}
         ref_b = S.collate(trees, 5)
         batch = R.to_torch_batch(ref_b)
         logits, glob = R.model_forward(W, hp, batch)
@@ -240,6 +240,13 @@ def test_bf16_large_config_at_full_depth_vs_fp32_oracle():
     # measured on MI355X: median 2.6e-2; every tensor but the deep pre-fusion query / key projections <= 7e-2; those (their |g| sits
     # AT the 1e-3 |g_value| floor: text layers 6-8) 7e-2 ... 1.07e-1
     is_qk = lambda n: any(t in n for t in (".query.", ".key.", ".q_proj.", ".k_proj."))
+    print("[C4F] worst query / key tensors: " + "; ".join(f"{n} {r:.3e}" for r, n, _, _ in [x for x in big if is_qk(x[1])][:4]))
+    # Round 4 measured what that q / k remnant's error is NOT: these text rows (48 tokens, one unbinned launch) ran on the fp32-scratch
+    # kernel before and run on attn_bwd_v4x now — both sum delta = sum P o dP in fp32 — and the table is the same to three digits
+    # (layer 7 query: 1.07e-1 in round 3, 1.067e-1 now).  So delta's rounding was never what these tensors see.  What is left is the
+    # bf16 STORAGE of q / k / v themselves: the value rows of a collapsed block differ by ~1e-3 of their norm, so dP_ij - delta_i =
+    # dO_i . (V_j - O_i) is a difference of bf16-rounded rows (2^-9 each) and a quarter of it is rounding — an fp32 oracle on the same
+    # weights keeps those activations in fp32.  Only storing qkv wider would remove it; the allowance for exactly these tensors stays.
     bad = [(n, r) for r, n, _, _ in big if r > (3 if is_qk(n) else 2) * BF16_GRAD_REL_L2]
     assert not bad, bad[:10]
 
