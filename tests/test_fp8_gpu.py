@@ -334,23 +334,25 @@ def test_fp8_producer_quantised_operands_equal_stand_alone_passes(monkeypatch):
 
 
 def test_fp8_training_learns_what_bf16_learns(capsys):
-    """Training-quality evidence for configs[4]: the launcher's learnable synthetic task (labels depend on
-    the labelled comment's text), a model wide enough for every fp8 site to engage (D 256, FFN 1024, 2 + 2 blocks), 120
-    updates from the SAME seed in bf16 and with fp8 operands at preset "all" (QKV / fc1 / fc2 forward, the input gradients of
-    fc2 and fc1; delayed scaling, producer-side quantisation).  Both must learn (training loss well below its start), the fp8
-    run's final training loss and held-out loss within 5 % of bf16's, held-out F1 within 0.03 (a handful of the 384 held-out
-    comments may sit on the decision boundary), accuracy within 0.02."""
+    """Training-quality evidence for configs[4]: the launcher's learnable synthetic task (a comment is hateful
+    iff its second token id lies in the upper half of the vocabulary) with a 64-word vocabulary, so that the rule GENERALISES from
+    the 640 labelled comments of the training stream to held-out trees; a model wide enough for every fp8 site to engage (D 256,
+    FFN 1024, 2 + 2 blocks); 160 updates from the SAME seed in bf16 and with fp8 operands at preset "all" (QKV / fc1 / fc2 forward,
+    the input gradients of fc2 and fc1; delayed scaling, producer-side quantisation).  Both must learn the rule (training loss
+    over the last 30 updates far below the first, held-out accuracy >= 0.9), and the fp8 run must learn what bf16 learns: mean
+    training loss of the last 30 updates within 5 % + 0.01, held-out loss within 5 % + 0.01, held-out F1 within 0.03 and accuracy
+    within 0.02 (3 of the 96 held-out comments)."""
     from multimodaldiscussiontransformer_amd import fp8, train
     base = ["--task", "node_prediction", "--arch", "multi_graphormer_base", "--criterion", "node_cross_entropy",
-            "--dataset-name", "synthetic", "--batch-size", "16", "--max-update", "120", "--validate-interval-updates", "120",
-            "--lr", "4e-4", "--end-learning-rate", "1e-5", "--warmup-updates", "8", "--total-num-update", "120",
+            "--dataset-name", "synthetic", "--batch-size", "16", "--max-update", "160", "--validate-interval-updates", "160",
+            "--lr", "4e-4", "--end-learning-rate", "1e-5", "--warmup-updates", "8", "--total-num-update", "160",
             "--adam-betas", "(0.9, 0.999)", "--adam-eps", "1e-8", "--weight-decay", "0.01",
             "--encoder-embed-dim", "256", "--encoder-ffn-embed-dim", "256", "--encoder-attention-heads", "4",
             "--num_fusion_layers", "1", "--num_bottleneck_tokens", "4", "--num_graph_stack", "1", "--num_fusion_stack", "1",
             "--attention-dropout", "0.1", "--act-dropout", "0.1", "--dropout", "0.1", "--spatial-pos-max", "5",
-            "--positive-weight", "1.5", "--negative-weight", "1", "--log-interval", "20",
-            "--synthetic-nodes", "8", "--synthetic-seq-len", "32", "--synthetic-batches", "6", "--synthetic-valid-batches", "3",
-            "--bert-config", '{"dim": 256, "layers": 4, "heads": 4, "intermediate": 1024, "vocab": 512, "max_pos": 64}',
+            "--positive-weight", "1.5", "--negative-weight", "1", "--log-interval", "1",
+            "--synthetic-nodes", "8", "--synthetic-seq-len", "32", "--synthetic-batches", "40", "--synthetic-valid-batches", "6",
+            "--bert-config", '{"dim": 256, "layers": 4, "heads": 4, "intermediate": 1024, "vocab": 64, "max_pos": 64}',
             "--vit-config", '{"dim": 256, "layers": 4, "heads": 4, "intermediate": 1024, "image_size": 32, "patch": 16}',
             "--no-save", "--seed", "7", "--random-init-encoders"]
     res = {}
@@ -359,17 +361,19 @@ def test_fp8_training_learns_what_bf16_learns(capsys):
             hist = train.main(base + extra)
             vh = train.main.valid_history[-1]
             st = train.main.last_run["fp8"]
-            res[tag] = dict(first=hist[0]["loss"], last=hist[-1]["loss"], vloss=vh["valid_loss"], f1=vh["valid_f1"], acc=vh["valid_accuracy"],
+            tail = [h["loss"] for h in hist[-30:]]
+            res[tag] = dict(first=hist[0]["loss"], last=sum(tail) / len(tail), vloss=vh["valid_loss"], f1=vh["valid_f1"], acc=vh["valid_accuracy"],
                             gemms=0 if st is None else st.gemms, fused=0 if st is None else st.fused_outputs)
     finally:
         fp8.ACTIVE = None
     capsys.readouterr()
     b, f = res["bf16"], res["fp8"]
-    print(f"[fp8 convergence] bf16: loss {b['first']:.4f} -> {b['last']:.4f}, held-out loss {b['vloss']:.4f} F1 {b['f1']:.4f} acc {b['acc']:.4f} | "
+    print(f"[fp8 convergence] bf16: loss {b['first']:.4f} -> {b['last']:.4f} (mean of the last 30 updates), held-out loss {b['vloss']:.4f} F1 {b['f1']:.4f} acc {b['acc']:.4f} | "
           f"fp8 all: loss {f['first']:.4f} -> {f['last']:.4f}, held-out loss {f['vloss']:.4f} F1 {f['f1']:.4f} acc {f['acc']:.4f}; "
           f"{f['gemms']} 8-bit GEMM launches, {f['fused']} operands quantised by their producer")
-    assert f["gemms"] > 120 * 10 and f["fused"] > 0, f           # the 8-bit kernels really carried the run
-    assert b["last"] < 0.7 * b["first"] and f["last"] < 0.7 * f["first"], (b, f)
-    assert abs(f["last"] - b["last"]) <= 0.05 * b["last"], (b["last"], f["last"])
-    assert abs(f["vloss"] - b["vloss"]) <= 0.05 * b["vloss"], (b["vloss"], f["vloss"])
+    assert f["gemms"] > 160 * 10 and f["fused"] > 0, f           # the 8-bit kernels really carried the run
+    assert b["last"] < 0.5 * b["first"] and f["last"] < 0.5 * f["first"], (b, f)
+    assert b["acc"] >= 0.9 and f["acc"] >= 0.9, (b, f)           # the rule was learnt, not memorised
+    assert abs(f["last"] - b["last"]) <= 0.05 * b["last"] + 0.01, (b["last"], f["last"])
+    assert abs(f["vloss"] - b["vloss"]) <= 0.05 * b["vloss"] + 0.01, (b["vloss"], f["vloss"])
     assert abs(f["f1"] - b["f1"]) <= 0.03 and abs(f["acc"] - b["acc"]) <= 0.02, (b, f)
