@@ -55,7 +55,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
             lang = ["-x", "hip"] if s.endswith(".cpp") else []
-            jobs.append([hipcc] + FLAGS + EXTRA.get(s, []) + lang + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + EXTRA.get(s, []) + os.environ.get("MDT_EXTRA_HIPCC_FLAGS", "").split() + lang + ["-c", src, "-o", obj])   # (experiment builds: -D switches)
 
     def run(cmd):
         if verbose:

@@ -99,6 +99,15 @@ __device__ __forceinline__ float row16_sum_dpp(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x121, 0xf, 0xf, true));   // row_ror:1
   return v;
 }
+// Sum over the 64 lanes, every lane gets the total, without a trip through the LDS crossbar (__shfl_xor = ds_bpermute_b32: six
+// dependent LDS round trips per sum): four DPP row rotations leave each 16-lane row with its own total, row_bcast:15 / row_bcast:31
+// carry the row totals upwards (lane 63 ends up with all four), v_readlane hands it to everybody as a scalar operand.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = row16_sum_dpp(v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ float row16_max(float v) {
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

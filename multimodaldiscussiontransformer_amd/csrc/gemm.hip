@@ -523,7 +523,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
   };
   auto issue_step = [&](const Desc& d, int hs, int buf) {
     char* st = smem + buf * PP_STAGE;
-    stage_step<A_KM, BM, 8>(d.rsA, lda_b, (int64_t)hs * 32, d.a_col0, st, wave, lane);
+    stage_step<A_KM, BM, 8, MDT_GEMM_A_AUX>(d.rsA, lda_b, (int64_t)hs * 32, d.a_col0, st, wave, lane);
     stage_step<B_KM, BN, 8>(d.rsB, ldb_b, (int64_t)hs * 32, d.b_col0, st + A_BYTES, wave, lane);
   };
   auto wait_pieces = [&](int halves) {
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto issue_piece = [&](const Desc& d, int sa, int sb, int buf, int q) __attribute__((always_inline)) {
     char* st = smem + buf * PP_STAGE;
     const int piece = wave + 4 * (q & 3);
-    if (q < 4) w4_dma(d.rsA, st + piece * 1024, voffA[q & 3], sa);
+    if (q < 4) w4_dma<MDT_GEMM_A_AUX>(d.rsA, st + piece * 1024, voffA[q & 3], sa);
     else w4_dma(d.rsB, st + A_BYTES + piece * 1024, voffB[q & 3], sb);
   };
   auto issue_step = [&](const Desc& d, int hs, int buf) {

@@ -125,7 +125,12 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int rc_base, i
 // swizzled by swz_km(k) as in the 64-k image (conflict-free ds_read_b64_tr_b16).
 __device__ __forceinline__ int swz_h(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
 
-template <bool KM, int ROWS, int NW>
+// AUX: cache-policy bits of the LDS-DMA request (1 = sc0, 2 = nt, 16 = sc1); MDT_GEMM_A_AUX (build-time, experiments) sets it for
+// the A operand of the persistent forward / input-gradient kernels — the streamed activation panels, read once per column group
+#ifndef MDT_GEMM_A_AUX
+#define MDT_GEMM_A_AUX 0
+#endif
+template <bool KM, int ROWS, int NW, int AUX = 0>
 __device__ __forceinline__ void stage_step(__amdgpu_buffer_rsrc_t rs, int64_t ld_bytes, int64_t k0, int col0,
                                            char* lds_tile, int wave, int lane) {
   constexpr int NPIECE = ROWS / 16;    // 1-KiB pieces per 32-k stage of one operand
@@ -145,7 +150,7 @@ __device__ __forceinline__ void stage_step(__amdgpu_buffer_rsrc_t rs, int64_t ld
       const int blk = (c16 >> 1) ^ swz_km(k);
       voff = (unsigned)((k0 + k) * ld_bytes + (col0 + blk * 16 + (c16 & 1) * 8) * 2);
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_tile + piece * 1024), 16, voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_tile + piece * 1024), 16, voff, 0, 0, AUX);
   }
 }
 
@@ -339,8 +344,9 @@ __device__ __forceinline__ bf16x8 w4_frag(const char* lds_tile, int rc_base, int
   }
 }
 
+template <int AUX = 0>
 __device__ __forceinline__ void w4_dma(__amdgpu_buffer_rsrc_t rs, char* lds, unsigned voff, int soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds), 16, voff, soff, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds), 16, voff, soff, 0, AUX);
 }
 
 

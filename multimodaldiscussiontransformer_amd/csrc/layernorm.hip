@@ -3,6 +3,8 @@
 // HBM-bound: algorithmic bytes = rows * D * sizeof(T) * 2 (fwd), * 3 (+ residual 4) (bwd).
 // Replaces fairseq LayerNorm / HF nn.LayerNorm (modules/graphormer_graph_encoder_layer.py:
 // 127-130,138-141; modules/multigraphormer_graph_encoder.py:400-403; HF BertLayer/ViTLayer).
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace mdt {
@@ -21,20 +23,31 @@ template <> struct Vec<bf16_t> {
   __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
 };
 
+// 8-byte vectors: D = 768 is 64 lanes x 12 elements = three 8-byte vectors per lane with EVERY lane busy; as 16-byte vectors it is one
+// and a half (the second one on lanes 0-31 only: a quarter of the row's arithmetic slots idle).  Wave instructions still cover
+// 512 contiguous bytes.
+template <typename T> struct VecH;
+template <> struct VecH<bf16_t> {
+  static constexpr int N = 4;
+  bf16x4 v;
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
+};
+
 // NV = number of 16-B vectors per lane: D = NV * 64 * Vec<T>::N exactly, or masked tail.
 // A wave walks rows wid, wid + nwaves, ...; the next row is requested before the current one is reduced, so a wave keeps
 // two rows (and an 8-workgroup CU 64 of them, ~100 KiB) in flight — with one row per wave and no look-ahead the kernel
 // moved 4.1 TB/s, bounded by bytes in flight over the ~2 us of an HBM round trip.
 // Q8 (bf16 only): y ALSO leaves as fp8 (1: e4m3, 2: e5m2) for the 8-bit GEMM that consumes it — q8 = saturate(bf16(y) * *q8_scale),
 // *q8_amax = max(*q8_amax, max |bf16(y)|), the bytes and the maximum mdt_fp8_quantize would make of y (fp8.hip), without its pass
-template <typename T, int NV, int Q8 = 0>
+template <typename T, int NV, int Q8 = 0, typename V = Vec<T>>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int D, const T* __restrict__ x, int64_t ldx,
                                                             const T* __restrict__ gamma, const T* __restrict__ beta,
                                                             float eps, T* __restrict__ y, int64_t ldy,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
                                                             uint8_t* __restrict__ q8 = nullptr, int64_t ldq = 0,
                                                             const float* __restrict__ q8_scale = nullptr, float* __restrict__ q8_amax = nullptr) {
-  constexpr int VN = Vec<T>::N;
+  constexpr int VN = V::N;
   const int lane = threadIdx.x & 63;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -46,14 +59,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int D,
     __syncthreads();
   }
   if (row < rows) {
-  Vec<T> gv[NV], bv[NV], xv[NV], xn[NV];
+  V gv[NV], bv[NV], xv[NV], xn[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * VN;
     if (c < D) {
-      xv[i] = *(const Vec<T>*)(x + row * ldx + c);
-      gv[i] = *(const Vec<T>*)(gamma + c);
-      bv[i] = *(const Vec<T>*)(beta + c);
+      xv[i] = *(const V*)(x + row * ldx + c);
+      gv[i] = *(const V*)(gamma + c);
+      bv[i] = *(const V*)(beta + c);
     }
   }
   for (;;) {
@@ -62,7 +75,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int D,
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * VN;
-        if (c < D) xn[i] = *(const Vec<T>*)(x + next * ldx + c);
+        if (c < D) xn[i] = *(const V*)(x + next * ldx + c);
       }
     }
     float s = 0.f;
@@ -74,7 +87,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int D,
         for (int j = 0; j < VN; ++j) s += xv[i].get(j);
       }
     }
-    const float mu = wave_sum(s) / (float)D;
+    const float mu = wave_sum_dpp(s) / (float)D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -84,35 +97,42 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int D,
         for (int j = 0; j < VN; ++j) { const float d = xv[i].get(j) - mu; q += d * d; }
       }
     }
-    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    const float rs = rsqrtf(wave_sum_dpp(q) / (float)D + eps);
     if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
     T* yr = y + row * ldy;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * VN;
       if (c < D) {
-        Vec<T> o;
+        V o;
 #pragma unroll
         for (int j = 0; j < VN; ++j) o.set(j, (xv[i].get(j) - mu) * rs * gv[i].get(j) + bv[i].get(j));
-        *(Vec<T>*)(yr + c) = o;
-        if constexpr (Q8 != 0 && VN == 8) {
+        *(V*)(yr + c) = o;
+        if constexpr (Q8 != 0 && (VN == 8 || VN == 4)) {
           constexpr float FMAX = Q8 == 1 ? 448.0f : 57344.0f;
-          float qv[8];
+          // mirrors fp8.hip: a NaN / infinity passes through as NaN (the MFMA propagates it to the loss) and marks the running
+          // maximum +inf, which fp8_scale_update leaves the scale alone for
+          float qv[VN];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
+          for (int j = 0; j < VN; ++j) {
             const float r = o.get(j);                 // the ROUNDED output
-            qmax = fmaxf(qmax, fabsf(r));
-            qv[j] = __builtin_amdgcn_fmed3f(r * qs, -FMAX, FMAX);
+            const bool bad = !(fabsf(r) <= 3.0e38f);
+            qmax = bad ? __builtin_inff() : fmaxf(qmax, fabsf(r));
+            const float xq = r * qs;
+            qv[j] = (xq != xq) ? xq : fminf(fmaxf(xq, -FMAX), FMAX);
           }
-          int w0 = 0, w1 = 0;
-          if constexpr (Q8 == 1) {
-            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[0], qv[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[2], qv[3], w0, true);
-            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[4], qv[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[6], qv[7], w1, true);
-          } else {
-            w0 = __builtin_amdgcn_cvt_pk_bf8_f32(qv[0], qv[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(qv[2], qv[3], w0, true);
-            w1 = __builtin_amdgcn_cvt_pk_bf8_f32(qv[4], qv[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(qv[6], qv[7], w1, true);
+          int w[VN / 4];
+#pragma unroll
+          for (int k = 0; k < VN / 4; ++k) {
+            w[k] = 0;
+            if constexpr (Q8 == 1) {
+              w[k] = __builtin_amdgcn_cvt_pk_fp8_f32(qv[4 * k], qv[4 * k + 1], w[k], false); w[k] = __builtin_amdgcn_cvt_pk_fp8_f32(qv[4 * k + 2], qv[4 * k + 3], w[k], true);
+            } else {
+              w[k] = __builtin_amdgcn_cvt_pk_bf8_f32(qv[4 * k], qv[4 * k + 1], w[k], false); w[k] = __builtin_amdgcn_cvt_pk_bf8_f32(qv[4 * k + 2], qv[4 * k + 3], w[k], true);
+            }
           }
-          *(int2*)(q8 + row * ldq + c) = make_int2(w0, w1);
+          if constexpr (VN == 8) *(int2*)(q8 + row * ldq + c) = make_int2(w[0], w[1]);
+          else *(int*)(q8 + row * ldq + c) = w[0];
         }
       }
     }
@@ -137,7 +157,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int D,
 // requested before the current row is reduced), keeps per-lane partial dgamma / dbeta / column sums in registers,
 // the block combines them through ONE [4 waves][row] LDS buffer used three times (16 KiB at D = 768: the 48 KiB of
 // three buffers held a CU to three workgroups) and issues one float atomic per column.
-template <typename T, int NV, bool TAIL, bool CS = TAIL>   // TAIL: second (dropped) output and / or column sums; CS: the column sums
+template <typename T, int NV, bool TAIL, bool CS = TAIL, typename V = Vec<T>>   // TAIL: second (dropped) output and / or column sums; CS: the column sums
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D, const T* __restrict__ dy, int64_t lddy,
                                                             const T* __restrict__ x, int64_t ldx,
                                                             const T* __restrict__ gamma, const float* __restrict__ mean,
@@ -146,22 +166,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int rows_per_wave, T* __restrict__ dxd, int64_t lddxd,
                                                             DropCfg drop, float* __restrict__ colsum) {
-  constexpr int VN = Vec<T>::N;
+  constexpr int VN = V::N;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = (float*)smem_raw;  // [4 waves][NV*64*VN]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
   const int64_t r1 = (r0 + rows_per_wave < rows) ? r0 + rows_per_wave : rows;
   float pg[NV][VN], pb[NV][VN], pc[CS ? NV : 1][CS ? VN : 1];
-  Vec<T> gv[NV];
+  V gv[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * VN;
-    if (c < D) gv[i] = *(const Vec<T>*)(gamma + c);
+    if (c < D) gv[i] = *(const V*)(gamma + c);
 #pragma unroll
     for (int j = 0; j < VN; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; if constexpr (CS) pc[i][j] = 0.f; }
   }
-  Vec<T> xv[NV], gy[NV], av[NV], xn[NV], gn[NV], an[NV];
+  V xv[NV], gy[NV], av[NV], xn[NV], gn[NV], an[NV];
   float mu = 0.f, rs = 0.f, mu_n = 0.f, rs_n = 0.f;
   if (r0 < r1) {
     mu = mean[r0]; rs = rstd[r0];
@@ -169,9 +189,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * VN;
       if (c < D) {
-        xv[i] = *(const Vec<T>*)(x + r0 * ldx + c);
-        gy[i] = *(const Vec<T>*)(dy + r0 * lddy + c);
-        if (add) av[i] = *(const Vec<T>*)(add + r0 * ldadd + c);
+        xv[i] = *(const V*)(x + r0 * ldx + c);
+        gy[i] = *(const V*)(dy + r0 * lddy + c);
+        if (add) av[i] = *(const V*)(add + r0 * ldadd + c);
       }
     }
   }
@@ -182,9 +202,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
       for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * VN;
         if (c < D) {
-          xn[i] = *(const Vec<T>*)(x + (row + 1) * ldx + c);
-          gn[i] = *(const Vec<T>*)(dy + (row + 1) * lddy + c);
-          if (add) an[i] = *(const Vec<T>*)(add + (row + 1) * ldadd + c);
+          xn[i] = *(const V*)(x + (row + 1) * ldx + c);
+          gn[i] = *(const V*)(dy + (row + 1) * lddy + c);
+          if (add) an[i] = *(const V*)(add + (row + 1) * ldadd + c);
         }
       }
     }
@@ -205,12 +225,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
         }
       }
     }
-    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+    const float m1 = wave_sum_dpp(s1) / (float)D, m2 = wave_sum_dpp(s2) / (float)D;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * VN;
       if (c < D) {
-        Vec<T> o, od;
+        V o, od;
         float ds0 = 0.f, ds1 = 0.f;
 #pragma unroll
         for (int j = 0; j < VN; ++j) {
@@ -230,9 +250,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
             if constexpr (CS) pc[i][j] += v;
           }
         }
-        *(Vec<T>*)(dx + row * lddx + c) = o;
+        *(V*)(dx + row * lddx + c) = o;
         if constexpr (TAIL) {
-          if (dxd) *(Vec<T>*)(dxd + row * lddxd + c) = od;
+          if (dxd) *(V*)(dxd + row * lddxd + c) = od;
         }
       }
     }
@@ -269,6 +289,17 @@ static int ln_fwd_dispatch(hipStream_t st, int64_t rows, int D, const void* x, i
   // 8 resident workgroups per CU (32 waves, two rows in flight each); short inputs get one row per wave
   const int64_t wgs = (rows + 3) / 4;
   const unsigned grid = (unsigned)(wgs < 2048 ? wgs : 2048);
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    if (D == 768) {          // three 8-byte vectors per lane, every lane busy (VecH)
+#define LN_FWD_H(Q_) hipLaunchKernelGGL((layernorm_fwd_kernel<T, 3, Q_, VecH<T>>), grid, 256, 0, st, rows, D, (const T*)x, ldx, (const T*)gamma, (const T*)beta, \
+                                        eps, (T*)y, ldy, mean, rstd, (uint8_t*)q8, ldq, q8_scale, q8_amax)
+      if (q8 && q8_fmt == 0) LN_FWD_H(1);
+      else if (q8) LN_FWD_H(2);
+      else LN_FWD_H(0);
+#undef LN_FWD_H
+      return check_launch("layernorm_fwd");
+    }
+  }
 #define LN_FWD(NV_)                                                                                          \
   if (q8 && q8_fmt == 0)                                                                                     \
     hipLaunchKernelGGL((layernorm_fwd_kernel<T, NV_, 1>), grid, 256, 0, st, rows, D, (const T*)x, ldx, (const T*)gamma, (const T*)beta, \
@@ -304,6 +335,18 @@ static int ln_bwd_dispatch(hipStream_t st, int64_t rows, int D, const void* dy, 
   if (rpw < 4) rpw = 4;
   const unsigned grid = (unsigned)((rows + 4 * rpw - 1) / (4 * rpw));
   const bool tail = dxd != nullptr || colsum != nullptr;
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    if (D == 768) {
+#define LN_BWD_H(TAIL_, CS_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, 3, TAIL_, CS_, VecH<T>>), grid, 256, (size_t)(4 * 768 * 4), st, rows, D, \
+                       (const T*)dy, lddy, (const T*)x, ldx, (const T*)gamma, mean, rstd, (const T*)add, ldadd,  \
+                       (T*)dx, lddx, dgamma, dbeta, rpw, (T*)dxd, lddxd, drop, colsum)
+      if (tail && !colsum) LN_BWD_H(true, false);
+      else if (tail) LN_BWD_H(true, true);
+      else LN_BWD_H(false, false);
+#undef LN_BWD_H
+      return check_launch("layernorm_bwd");
+    }
+  }
 #define LN_BWD(NV_)                                                                                              \
   if (tail && !colsum)                                                                                           \
     hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV_, true, false>), grid, 256, (size_t)(4 * NV_ * 64 * VN * 4), st, rows, D, \
