@@ -823,8 +823,9 @@ __device__ __forceinline__ bf16x8 v2_frag_tr_ld(const bf16_t* img, int ld, int t
 // gradient scale but is what is LEFT of the query / key gradients where the softmax is nearly uniform (C4F fixture: |g_query| at
 // 1e-3 ... 1e-5 of |g_value|, tests/test_real_shapes_gpu.py).  A wave owns one key tile and at most three query-tile pairs, so
 // phase 1 runs as two sweeps with P and dP of all its pairs held in registers (48): sweep A forms them, sums p * dP over the
-// wave's 16 keys (four DPP row rotations) and adds the row sums to the delta image in LDS (ds_add_f32, one lane per row group);
-// behind a workgroup barrier sweep B forms dS with the finished delta.  The output of the forward is not read at all.
+// wave's 16 keys (four DPP row rotations) and stores the row sums in ITS slab of the delta image in LDS; behind a workgroup
+// barrier sweep B adds the slabs of all key tiles in tile order (bitwise reproducible) and forms dS.  The output of the forward is
+// not read at all.
 constexpr int V4_EXACT_PAIRS = 3;
 template <int HD, bool DROP, bool EXACT>
 __device__ __forceinline__ void attn_bwd_v4_body(const AttnParams& P, int rows_img, int ldq) {
@@ -847,8 +848,8 @@ __device__ __forceinline__ void attn_bwd_v4_body(const AttnParams& P, int rows_i
   bf16_t* img1 = img0 + rows_img * V2_LD;              // dO
   float* s_kb = (float*)(img1 + rows_img * V2_LD);
   float* s_lse = s_kb + rows_img;
-  float* s_delta = s_lse + rows_img;
-  bf16_t* dsT = (bf16_t*)(s_delta + rows_img);         // [16 * tiles][ldq]: dS^T, key-major
+  float* s_delta = s_lse + rows_img;                   // EXACT: [8 key tiles][rows_img] partial row sums, one slab per wave
+  bf16_t* dsT = (bf16_t*)(s_delta + rows_img * (EXACT ? 8 : 1));   // [16 * tiles][ldq]: dS^T, key-major
   BiasCtx bc{seq, h, S, a.H, a.key_mask, a.key_pad, a.dense_bias, a.attn_bias, a.spatial_pos, a.sp_table, a.virt};
   const int n_t = (S + 15) >> 4;
   const int rows_live = ((n_t + 1) >> 1) * 32;         // this sequence's rows, in pairs of tiles (zero rows past S)
@@ -973,10 +974,9 @@ __device__ __forceinline__ void attn_bwd_v4_body(const AttnParams& P, int rows_i
               dA[pr][t][r] = dpv;
               x[r] = row16_sum_dpp(p * dpv);          // over the 16 keys of this tile: every lane of the row group holds it
             }
-            if (c == 0) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) atomicAdd(s_delta + qb + r, x[r]);      // ds_add_f32: the key tiles of the other waves add theirs
-            }
+            // this key tile's slab of partial sums (plain stores, summed in a FIXED order by the readers: LDS atomics would make
+            // delta — and through one-ulp flips of dS the whole step — depend on the order the waves arrive in)
+            if (c == 0) *(f32x4*)(s_delta + kt * rows_img + qb) = f32x4{x[0], x[1], x[2], x[3]};
           }
         }
       }
@@ -989,7 +989,8 @@ __device__ __forceinline__ void attn_bwd_v4_body(const AttnParams& P, int rows_i
           f32x4 sc[2], dp[2];
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            const f32x4 dlv = *(const f32x4*)(s_delta + (t0 + t) * 16 + 4 * g);
+            f32x4 dlv = *(const f32x4*)(s_delta + (t0 + t) * 16 + 4 * g);
+            for (int w = 1; w < n_t; ++w) dlv += *(const f32x4*)(s_delta + w * rows_img + (t0 + t) * 16 + 4 * g);     // key tiles in order
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float p = pA[pr][t][r];
@@ -1424,7 +1425,8 @@ static size_t v4_lds_bytes(int S, int* rows_img, int* ldq) {
   const int n_t = (S + 15) / 16;
   *rows_img = ((n_t + 1) / 2) * 32;
   *ldq = (n_t & 1) ? 16 * n_t : 16 * n_t + 16;        // ldq / 2 = 8 (mod 16) banks: rows 0-7 of a transposed read fall on distinct 8-bank groups
-  const size_t b = (size_t)2 * *rows_img * V2_LD * 2 + (size_t)3 * *rows_img * 4 + (size_t)16 * n_t * *ldq * 2;
+  const size_t slabs = n_t <= 2 * V4_EXACT_PAIRS ? 7 : 0;      // attn_bwd_v4x: seven more slabs of per-key-tile row sums
+  const size_t b = (size_t)2 * *rows_img * V2_LD * 2 + (size_t)(3 + slabs) * *rows_img * 4 + (size_t)16 * n_t * *ldq * 2;
   return b <= 160 * 1024 ? b : 0;
 }
 

@@ -390,6 +390,16 @@ class DataParallel:
         finally:
             b.defer = False
         out["ok"] = bool(out["replicas_equal"] and out["finite"] and out["overlapped_vs_deferred_rel_l2"] < 1e-4 and out["bucketed_vs_flat_rel_l2"] < 1e-4)
+        if not out["ok"]:
+            # name the parameters that differ most between the runs (what a failure report needs first)
+            names = {id(p): n for n, p in self.model.named_parameters()}
+            rows = []
+            for pid, off, span in b.slots:
+                a1, a2, a3 = g1[off:off + span], g2[off:off + span], g3[off:off + span]
+                d = float(a3.norm()) + 1e-30
+                rows.append((max(float((a1 - a2).norm()), float((a2 - a3).norm())) / d, names.get(pid, "?"), float(a3.norm())))
+            rows.sort(reverse=True)
+            out["worst_parameters"] = [(n, round(r, 6), float(f"{gn:.3g}")) for r, n, gn in rows[:8]]
         return out
 
     def diagnostics(self) -> dict:

@@ -1,0 +1,37 @@
+"""Two processes share the card: the condition under which round 4 found an intermittent garbage tile in the persistent GEMMs
+(tools/finite_hunt.py: a counted `s_waitcnt vmcnt(N)` assumed that requests answered without going to memory — all 64 lanes
+outside the buffer descriptor: the zero-record descriptor behind the last tile, rows past M of a ragged tile, the stand-in
+stores of a first tile — stay in the count; they leave it at once, and when a second tenant makes the loads slow an older
+LDS-DMA piece is let through unlanded).  Each process repeats the same training step with every kernel output checked for
+non-finite / absurd values and the step's gradients compared across repetitions."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(os.environ.get("MDT_SKIP_MULTIPROC") == "1", reason="MDT_SKIP_MULTIPROC=1")
+def test_training_step_is_clean_and_repeatable_beside_a_second_tenant():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="4")
+    env.pop("MDT_BENCH_OFFICIAL", None)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", tool)] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True)
+             for tool, args in (("finite_hunt.py", ["--reps", "30", "--tag", "hunt"]), ("step_determinism.py", ["--reps", "12", "--tag", "det"]))]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+            pytest.fail("a tenant did not finish in 400 s:\n" + out[-2000:])
+        outs.append(out)
+    hunt, det = outs
+    assert "steps clean" in hunt and "FIRST BAD OUTPUT" not in hunt and "arena bad" not in hunt, hunt[-3000:]
+    worst = [l for l in det.splitlines() if "WORST" in l]
+    assert worst and "NON-FINITE" not in det, det[-3000:]
+    assert float(worst[0].split("WORST")[1]) < 1e-5, det[-3000:]         # repetitions differ by fp32 atomic order only (~1e-7)
