@@ -5,7 +5,7 @@ K = D contractions into a wide output, measured on MI355X at C2 shapes (tools/fp
 (1.26 x including the pass), fc1 (1.23 x) and, in backward, fc2's input gradient dY W2 (same shape class).  The output
 projection and fc2 forward (narrow N, or a 4 D-wide activation to quantise) lose to bf16 with a stand-alone pass and stay
 in bf16, as do all weight gradients (fp32 accumulation into the gradient arena) — fusing the quantisation into the
-producing kernels (LayerNorm, attention, GELU epilogue) is what would bring those in.
+producing kernels (LayerNorm, attention, GELU epilogue) is what would bring those in (docs/experiment_log.md §9).
 
 Since round 3 the 8-bit GEMMs with K a multiple of 128 run on the block MFMA v_mfma_f32_16x16x128_f8f6f4 (csrc/gemm_f8.hip: twice
 the bf16 MFMA rate), and two of them hand their OUTPUT to the next GEMM already quantised, from their own epilogue

@@ -1,6 +1,6 @@
 """Static checks on the gfx950 assembly of the 4-wave GEMM kernels (gemm_bf16_w4p, and the 8-bit gemm_f8_w4 built the same way): their MFMAs are asm statements, which hides
 them from the compiler's hazard recognizer, and three things that went wrong on the GPU because of that are visible in the
-instruction stream ("three traps").  The checks read the disassembly of the object the in-tree build produced (no GPU needed).
+instruction stream (docs/experiment_log.md §4, "three traps").  The checks read the disassembly of the object the in-tree build produced (no GPU needed).
 
   1. no accumulator read (v_accvgpr_read) inside or right behind the MFMA stream of a step;
   2. no 16-byte buffer store whose data registers are rewritten by the next instructions (hipcc does not protect MUBUF

@@ -1,6 +1,6 @@
 """Bitwise repeatability of the persistent GEMM launches (the same launch N times: any difference is a race).  Written after
 tests/test_dropout_gpu.py::test_gemm_saved_derivative_epilogue[dtype2-shape2] was seen to fail intermittently on one box
-(DESIGN.md §12).  GPU box only."""
+(docs/experiment_log.md §12).  GPU box only."""
 import sys
 
 import torch

@@ -1,4 +1,4 @@
-"""Deterministic stress of the 8-wave persistent GEMM (gemm_bf16_pp256p) — VERDICT r3 item 1, DESIGN.md §12.
+"""Deterministic stress of the 8-wave persistent GEMM (gemm_bf16_pp256p) — VERDICT r3 item 1, DESIGN.md §4 (history: docs/experiment_log.md §12).
 
 Every case is ONE launch shape with slightly more 256 x 256 tiles than compute units (so some workgroups walk a tile boundary with the
 ring still turning) at a short or long K loop.  The launch is repeated `reps` times in two builds of the same source:
