@@ -209,7 +209,7 @@ def load_checkpoint(path: str, model, *, optimizer=None, reset_optimizer: bool =
     if strict and (missing or res.unexpected_keys):
         raise RuntimeError(f"{path}: missing keys {missing[:8]}{'...' if len(missing) > 8 else ''}, "
                            f"unexpected keys {list(res.unexpected_keys)[:8]}")
-    out = dict(num_updates=0, lr_scheduler_state={}, epoch=1, extra_state={}, missing=list(res.missing_keys),
+    out = dict(num_updates=0, lr_scheduler_state={}, epoch=1, iterations_in_epoch=0, extra_state={}, missing=list(res.missing_keys),
                unexpected=list(res.unexpected_keys), loaded_optimizer=False)
     hist = state.get("optimizer_history") or []
     if optimizer is not None and not reset_optimizer and state.get("last_optimizer_state") is not None and hist:
@@ -221,8 +221,10 @@ def load_checkpoint(path: str, model, *, optimizer=None, reset_optimizer: bool =
     extra = state.get("extra_state") or {}
     if not reset_meters:
         out["extra_state"] = extra
-    if not reset_dataloader:
-        out["epoch"] = int((extra.get("train_iterator") or {}).get("epoch", 1))
+    if not reset_dataloader:      # FairSeq ties the iterator state (epoch AND position inside it) to --reset-dataloader alone
+        it = extra.get("train_iterator") or {}
+        out["epoch"] = int(it.get("epoch", 1))
+        out["iterations_in_epoch"] = int(it.get("iterations_in_epoch", 0) or 0)
     from . import engine
     engine.weights_changed()          # cached transposed weight copies (engine.dgrad) are stale
     return out

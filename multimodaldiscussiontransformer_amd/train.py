@@ -199,7 +199,7 @@ def main(argv=None):
 
     skip_batches = 0          # batches of the running epoch that the restored checkpoint had already consumed
     if args.restore_file and not args.reset_dataloader:
-        skip_batches = int(((info["extra_state"].get("train_iterator") or {}).get("iterations_in_epoch", 0)) or 0)
+        skip_batches = int(info.get("iterations_in_epoch", 0))      # (not read from extra_state: --reset-meters empties that, and must not rewind the data)
     valid_batches = None      # callable → iterable of packed batches of the held-out split (this rank's share)
     if args.dataset_name == "synthetic":
         batches = synthetic_batches(args, task, rank)
