@@ -212,10 +212,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_tile256(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int a_rows = A_KM ? BM : (int)(p.M - m0 < BM ? p.M - m0 : BM);      // rows of this tile that exist
   auto issue = [&](int kt) {
     char* st = smem + (kt % NSTAGE) * STAGE;
-    stage_tile<A_KM, BM, 8>(rsA, lda_b, a_k0 + (int64_t)kt * T_BK, a_col0, st, wave, lane, a_rows);
+    stage_tile<A_KM, BM, 8>(rsA, lda_b, a_k0 + (int64_t)kt * T_BK, a_col0, st, wave, lane);
     stage_tile<B_KM, BN, 8>(rsB, ldb_b, b_k0 + (int64_t)kt * T_BK, b_col0, st + A_BYTES, wave, lane);
   };
 #pragma unroll
@@ -349,10 +348,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256(GemmParams p) {
   const bf16x8 ones = bf16x8{(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
 
   // step hs (32 k) -> ring buffer `buf`: 4 LDS-DMA pieces per wave (2 of A, 2 of B)
-  const int a_rows = A_KM ? BM : (int)(p.M - m0 < BM ? p.M - m0 : BM);      // rows of this tile that exist
   auto issue_step = [&](int hs, int buf) {
     char* st = smem + buf * PP_STAGE;
-    stage_step<A_KM, BM, 8>(rsA, lda_b, a_k0 + (int64_t)hs * 32, a_col0, st, wave, lane, a_rows);
+    stage_step<A_KM, BM, 8>(rsA, lda_b, a_k0 + (int64_t)hs * 32, a_col0, st, wave, lane);
     stage_step<B_KM, BN, 8>(rsB, ldb_b, b_k0 + (int64_t)hs * 32, b_col0, st + A_BYTES, wave, lane);
   };
   auto wait_pieces = [&](int halves) {           // all but the youngest `halves` steps of this wave have landed
@@ -482,7 +480,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
   const int nhs = (int)((p.K * ESZ + 63) / 64);           // 64-byte steps
   const int64_t lda_b = p.lda * ESZ, ldb_b = p.ldb * ESZ;
 
-  struct Desc { __amdgpu_buffer_rsrc_t rsA, rsB; int a_col0, b_col0; int64_t m0, n0; int a_rows; };
+  struct Desc { __amdgpu_buffer_rsrc_t rsA, rsB; int a_col0, b_col0; int64_t m0, n0; };
   auto make_desc = [&](int v) {
     const int q8 = nvt >> 3, r8 = nvt & 7, xcd = v & 7;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3);
@@ -521,12 +519,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp256p(GemmParams p) {
     d.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, b_rec, 0x00020000);
     d.a_col0 = A_KM ? (int)lm0 : 0;
     d.b_col0 = B_KM ? (int)ln0 : 0;
-    d.a_rows = A_KM ? BM : (int)(p.M - lm0 < BM ? p.M - lm0 : BM);      // rows of this tile that exist (stage_tile: every request a real one)
     return d;
   };
   auto issue_step = [&](const Desc& d, int hs, int buf) {
     char* st = smem + buf * PP_STAGE;
-    stage_step<A_KM, BM, 8, MDT_GEMM_A_AUX>(d.rsA, lda_b, (int64_t)hs * 32, d.a_col0, st, wave, lane, d.a_rows);
+    stage_step<A_KM, BM, 8, MDT_GEMM_A_AUX>(d.rsA, lda_b, (int64_t)hs * 32, d.a_col0, st, wave, lane);
     stage_step<B_KM, BN, 8>(d.rsB, ldb_b, (int64_t)hs * 32, d.b_col0, st + A_BYTES, wave, lane);
   };
   auto wait_pieces = [&](int halves) {
@@ -721,8 +718,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int nhs = (int)((p.K + 31) / 32);
   const int64_t lda_b = p.lda * 2, ldb_b = p.ldb * 2;
 
-  // a_last: per-lane A offsets are clamped to the start of the tile's last valid row (see issue_piece)
-  struct Desc { __amdgpu_buffer_rsrc_t rsA, rsB; int a_col0, b_col0; int64_t m0, n0; unsigned a_last, a_end; };
+  struct Desc { __amdgpu_buffer_rsrc_t rsA, rsB; int a_col0, b_col0; int64_t m0, n0; };
   auto make_desc = [&](int v) {
     const int q8 = nvt >> 3, r8 = nvt & 7, xcd = v & 7;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3);
@@ -745,12 +741,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     Desc d;
     d.m0 = (int64_t)tm * BM;
     d.n0 = (int64_t)tn * BN;
-    {
-      const int64_t rows_left = p.M - d.m0;
-      const int64_t rows_valid = rows_left < BM ? rows_left : BM;
-      d.a_end = A_KM ? 0xFFFFFFFFu : (unsigned)(rows_valid * lda_b);       // offsets of rows past the tile's last valid one start here
-      d.a_last = (unsigned)((rows_valid - 1) * lda_b);
-    }
     const char* a_base;
     const char* b_base;
     int64_t a_bytes, b_bytes;
@@ -793,13 +783,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto issue_piece = [&](const Desc& d, int sa, int sb, int buf, int q) __attribute__((always_inline)) {
     char* st = smem + buf * PP_STAGE;
     const int piece = wave + 4 * (q & 3);
-    // Every request must be a REAL memory operation: the counted vmcnt waits below assume that what they leave in flight is
-    // still in flight, and a request whose 64 lanes all fall outside the descriptor (rows past M of a ragged last row tile, a
-    // descriptor of zero records) is answered without going to memory — it leaves the counter early, and a wait that counted on
-    // it lets an OLDER piece through unlanded (round 4: one garbage tile in ~1000 launches when a second process shared the
-    // card and the loads were slow; tools/finite_hunt.py).  So rows past the tile's last valid row read that row's start
-    // instead (valid bytes in the wrong k order: those output rows are never stored).
-    if (q < 4) w4_dma<MDT_GEMM_A_AUX>(d.rsA, st + piece * 1024, voffA[q & 3] < d.a_end ? voffA[q & 3] : d.a_last, sa);
+    if (q < 4) w4_dma<MDT_GEMM_A_AUX>(d.rsA, st + piece * 1024, voffA[q & 3], sa);
     else w4_dma(d.rsB, st + A_BYTES + piece * 1024, voffB[q & 3], sb);
   };
   auto issue_step = [&](const Desc& d, int hs, int buf) {
@@ -832,10 +816,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
 #define W4_STAMP(slot_) (void)0
 #endif
-  // after the last tile the ring keeps turning on the SAME tile's first stages again (nobody reads them): the loop needs no
-  // "nothing left to request" case, the vmcnt arithmetic is the same in every step — and the requests are real ones (a
-  // descriptor of zero records, as round 2-3 used here, answers at once and falls out of the count the waits rely on)
-  auto null_desc = [&](Desc d) { return d; };
+  // after the last tile the ring keeps turning on a descriptor of zero records (every load reads as 0, nobody reads the
+  // stage): the loop needs no "nothing left to request" case and the vmcnt arithmetic is the same in every step
+  auto null_desc = [&](Desc d) {
+    d.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
+    d.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0, 0x00020000);
+    return d;
+  };
   Desc nxt = has_next ? make_desc(v_next) : null_desc(cur);
 #pragma unroll
   for (int h = 0; h < PP_DIST; ++h) issue_step(cur, h, h);        // host guarantees nhs >= PP_DIST
@@ -867,8 +854,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // Steps 0-2 of a tile count the epilogue's W4_DS direct stores among the operations that may still be in flight (they are
     // younger than the LDS-DMA pieces those steps wait for; without counting them the steps would wait for the stores'
     // acknowledgements instead).  A workgroup's first tile has no epilogue before it: W4_DS dropped stores stand in.
+    // They MUST be asm statements.  As builtin stores (rounds 2-3) the sixteen identical stores — same data, same address, same
+    // descriptor — were merged into ONE by the compiler, so steps 0-2 of every workgroup's FIRST tile waited with a budget that
+    // was 15 too large: vmcnt(32) against 25 operations in flight is no wait at all, and the first fragments were read from a
+    // stage that need not have landed.  On an idle card the cold loads are in LDS long before; with a second tenant on the card
+    // (or a slow box) they are not: one garbage 256 x 256 tile in ~1000 launches — round 3's "box-dependent" failures, round 4's
+    // failing exchange self-check (tools/finite_hunt.py found the tile, tools/probes/vmcnt_order_probe.hip cleared the counter
+    // itself: vmcnt retires strictly in issue order, dropped requests included).  tests/test_isa_hazards_cpu.py counts them.
+#if defined(__HIP_DEVICE_COMPILE__)
+    const i32x4 zero4 = i32x4{0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < W4_DS; ++i) __builtin_amdgcn_raw_buffer_store_b128(i32x4{0, 0, 0, 0}, rsP, voffP, 0, 0);
+    for (int i = 0; i < W4_DS; ++i) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(zero4), "v"(voffP), "s"(rsP) : "memory");
+#endif
   }
   auto desc_c = [&](const Desc& d) {
     const int64_t bytes = (p.M - d.m0) * p.ldc * 2 - d.n0 * 2;
@@ -886,22 +883,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
 #define W4_MF(i_, j_) (void)first
 #endif
-  // cons: the stores this tile's budgets count as "still in flight" are not real ones — a workgroup's first tile (its stand-in
-  // and pending stores go through a descriptor of zero records) and the tile behind a ragged one (whose stores for rows past M
-  // are dropped): only the LDS-DMA pieces of the two steps in between are counted then
-  bool cons = true;
   auto step = [&](auto cs_c, auto first_c, auto nw_c, auto st_c, auto ld_c, const Desc& d_issue, int hs_issue) __attribute__((always_inline)) {
     constexpr int cs = decltype(cs_c)::value, ns = cs ^ 1;
     constexpr bool first = decltype(first_c)::value;
     constexpr int NW = decltype(nw_c)::value, ST = decltype(st_c)::value;
     constexpr bool LD = decltype(ld_c)::value;       // false in a tile's last step: the next tile's first fragments are read after the epilogue
     const int sa = soff_a(d_issue, hs_issue), sb = soff_b(d_issue, hs_issue);
-    if constexpr (NW > 16) {                      // own pieces of the next step have landed
-      if (cons) wait_vm<16>();
-      else wait_vm<NW>();
-    } else {
-      wait_vm<NW>();
-    }
+    wait_vm<NW>();                                // own pieces of the next step have landed
     __builtin_amdgcn_s_barrier();                 // ... and everybody's; the stage of the previous step is free
     const char* tn = smem + b_next * PP_STAGE;
 #pragma unroll
@@ -1023,7 +1011,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
     if (!has_next) break;
-    cons = p.M - cur.m0 < BM;                     // a ragged tile's stores for rows past M never reach memory
     cur = nxt;
     v += gridDim.x;
     v_next = v + (int)gridDim.x < nvt ? v + (int)gridDim.x : -1;

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int nsp = nst >> 1;                           // 128-k steps
   const int64_t lda_b = p.lda, ldb_b = p.ldb;         // bytes: one per element
 
-  struct Desc { __amdgpu_buffer_rsrc_t rsA, rsB; int64_t m0, n0; unsigned a_last, a_end; };    // a_end / a_last: see issue_piece
+  struct Desc { __amdgpu_buffer_rsrc_t rsA, rsB; int64_t m0, n0; };
   auto make_desc = [&](int v) {
     const int q8 = nvt >> 3, r8 = nvt & 7, xcd = v & 7;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3);
@@ -85,11 +85,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     Desc d;
     d.m0 = (int64_t)tm * BM;
     d.n0 = (int64_t)tn * BN;
-    {
-      const int64_t rows_left = p.M - d.m0, rows_valid = rows_left < BM ? rows_left : BM;
-      d.a_end = (unsigned)(rows_valid * lda_b);
-      d.a_last = (unsigned)((rows_valid - 1) * lda_b);
-    }
     const int64_t a_bytes = (p.M - d.m0) * lda_b, b_bytes = (p.N - d.n0) * ldb_b;
     const unsigned a_rec = (unsigned)(a_bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : a_bytes);
     const unsigned b_rec = (unsigned)(b_bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : b_bytes);
@@ -108,10 +103,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto issue_piece = [&](const Desc& d, int soff, int buf, int q) __attribute__((always_inline)) {
     char* st = smem + buf * PP_STAGE;
     const int piece = wave + 4 * (q & 3);
-    // every request a REAL memory operation (gemm.hip, gemm_bf16_w4p issue_piece): rows past the tile's last valid row read that
-    // row's start — a request with all 64 lanes outside the descriptor is answered without going to memory and leaves the vmcnt
-    // count the waits below rely on
-    if (q < 4) w4_dma(d.rsA, st + piece * 1024, voffA[q & 3] < d.a_end ? voffA[q & 3] : d.a_last, soff);
+    if (q < 4) w4_dma(d.rsA, st + piece * 1024, voffA[q & 3], soff);
     else w4_dma(d.rsB, st + A_BYTES + piece * 1024, voffB[q & 3], soff);
   };
 
@@ -119,7 +111,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   int v_next = v + (int)gridDim.x < nvt ? v + (int)gridDim.x : -1;
   Desc cur = make_desc(v);
   bool has_next = v_next >= 0;
-  auto null_desc = [&](Desc d) { return d; };        // after the last tile the ring keeps turning on the same tile's first stages (real requests; nobody reads them)
+  auto null_desc = [&](Desc d) {        // after the last tile the ring keeps turning on descriptors of zero records
+    d.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
+    d.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0, 0x00020000);
+    return d;
+  };
   Desc nxt = has_next ? make_desc(v_next) : null_desc(cur);
 
   // fragment reads: row (lane & 15) of a 16-row block, chunk (lane >> 4) swizzled by the row, in both stages of the pair
@@ -161,8 +157,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if constexpr (PEND) {
     // a tile's first barriers count the epilogue's direct stores among what may be in flight; a workgroup's first tile has no
     // epilogue before it: dropped stores (descriptor of zero records) stand in, so the arithmetic is the same for every tile
+    // asm statements: as builtins the identical stores were merged into one by the compiler and the first tile's budgets were
+    // too large by all the others (gemm.hip, gemm_bf16_w4p)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const i32x4 zero4 = i32x4{0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < F8W_DS + AUXDS; ++i) __builtin_amdgcn_raw_buffer_store_b128(i32x4{0, 0, 0, 0}, rsP, voffP, 0, 0);
+    for (int i = 0; i < F8W_DS + AUXDS; ++i) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(zero4), "v"(voffP), "s"(rsP) : "memory");
+#endif
   }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -177,9 +178,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // pending vectors ST .. ST + 3 leave; LD: pass 1 refills the fragments (false in a tile's last step: the next tile's first
   // fragments are read after the epilogue).  d0 / s0: descriptor and byte offset of the stage requested in pass 0 (stage
   // 2P + 4), d1 / s1: in pass 1 (stage 2P + 5).
-  // cons: a workgroup's first tile (stand-in and pending stores through a descriptor of zero records) and the tile behind a ragged one
-  // (stores of rows past M dropped): stores the budgets count as in flight that never went to memory — only the pieces are counted
-  bool cons = true;
   auto step = [&](auto first_c, auto nw_c, auto st_c, auto ld_c, const Desc& d0, int s0, const Desc& d1, int s1) __attribute__((always_inline)) {
     constexpr bool first = decltype(first_c)::value;
     constexpr int NW = decltype(nw_c)::value, ST = decltype(st_c)::value;
@@ -199,12 +197,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }, std::make_integer_sequence<int, 8>{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own reads of this pair are done
-    if constexpr (NW > 8) {                              // own pieces of stage 2P + 3 (requested in pass 1 of the step before) have landed
-      if (cons) wait_vm<8>();                            // (cons: the stores the budget counts are not real ones, see below)
-      else wait_vm<NW>();
-    } else {
-      wait_vm<NW>();
-    }
+    wait_vm<NW>();                                       // own pieces of stage 2P + 3 (requested in pass 1 of the step before) have landed
     __builtin_amdgcn_s_barrier();                        // ... and everybody's; this pair's two buffers are free
     // ---- pass 1: column blocks 4-7; the next pair's A and column blocks 0-3 arrive; stage 2P + 5 is requested into the buffer of stage 2P
     f8w_unroll([&](auto bc) __attribute__((always_inline)) {
@@ -302,7 +295,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
     if (!has_next) break;
-    cons = p.M - cur.m0 < BM;
     cur = nxt;
     v += gridDim.x;
     v_next = v + (int)gridDim.x < nvt ? v + (int)gridDim.x : -1;

@@ -75,14 +75,9 @@ __device__ __forceinline__ int swz_km(int k) { return (k & 3) | (((k >> 3) & 1) 
 // Issue the LDS-DMA loads of one operand tile of ROWS rows|columns x 64 k (ROWS = 128 or 256):
 // ROWS/8 pieces of 1 KiB, dealt round-robin to the NW waves of the block.
 //   k-contiguous: piece = 8 rows x 128 B;  k-major: piece = (1024 / (2*ROWS)) k-rows x 2*ROWS B.
-// rows_valid (k-contiguous operands): rows of the tile that exist (M - m0 for a ragged last row tile).  Rows past them read the last
-// valid row instead of falling outside the descriptor: a request whose 64 lanes are ALL out of range is answered without going to
-// memory and leaves the vmcnt count early — the kernels that wait with a COUNTED vmcnt (everything they leave in flight must
-// really be in flight) then let an older piece through unlanded when loads are slow (round 4, tools/finite_hunt.py).  The rows
-// hold valid bytes in the wrong k order; their outputs are never stored.
 template <bool KM, int ROWS, int NW>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, int64_t ld_bytes, int64_t k0, int col0,
-                                           char* lds_tile, int wave, int lane, int rows_valid = ROWS) {
+                                           char* lds_tile, int wave, int lane) {
   constexpr int NPIECE = ROWS / 8;
 #pragma unroll
   for (int i = 0; i < NPIECE / NW; ++i) {
@@ -91,8 +86,7 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, int64_t ld
     if constexpr (!KM) {
       const int row = piece * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ swz_kc(row);
-      const int rowc = row < rows_valid ? row : rows_valid - 1;
-      voff = (unsigned)(rowc * ld_bytes + (k0 + chunk * 8) * 2);
+      voff = (unsigned)(row * ld_bytes + (k0 + chunk * 8) * 2);
     } else {
       constexpr int C16 = ROWS / 8;        // 16-B chunks per k-row
       constexpr int KPP = 64 / C16;        // k-rows per piece
@@ -138,7 +132,7 @@ __device__ __forceinline__ int swz_h(int row) { return (0x78 >> (2 * ((row >> 2)
 #endif
 template <bool KM, int ROWS, int NW, int AUX = 0>
 __device__ __forceinline__ void stage_step(__amdgpu_buffer_rsrc_t rs, int64_t ld_bytes, int64_t k0, int col0,
-                                           char* lds_tile, int wave, int lane, int rows_valid = ROWS) {
+                                           char* lds_tile, int wave, int lane) {
   constexpr int NPIECE = ROWS / 16;    // 1-KiB pieces per 32-k stage of one operand
 #pragma unroll
   for (int i = 0; i < NPIECE / NW; ++i) {
@@ -147,8 +141,7 @@ __device__ __forceinline__ void stage_step(__amdgpu_buffer_rsrc_t rs, int64_t ld
     if constexpr (!KM) {
       const int row = piece * 16 + (lane >> 2);
       const int chunk = (lane & 3) ^ swz_h(row);
-      const int rowc = row < rows_valid ? row : rows_valid - 1;       // see stage_tile
-      voff = (unsigned)(rowc * ld_bytes + (k0 + chunk * 8) * 2);
+      voff = (unsigned)(row * ld_bytes + (k0 + chunk * 8) * 2);
     } else {
       constexpr int C16 = ROWS / 8;        // 16-B chunks per k-row
       constexpr int KPP = 64 / C16;        // k-rows per piece

@@ -154,20 +154,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4S_MB(q_, i_) accb[q_] = mfma_bf16(fa[cs][i_], ones, accb[q_])
   // one 32-k step on fragment set cs: FIRST starts the accumulators from zero; NW = vector-memory operations that may still be
   // in flight when the step begins; LD: read the next step's fragments; IS: request step hs_issue into the ring
-  int step_no = 0;
-  const int drain_from = ((kend - kbeg) & 63) ? nhs - 6 : 0x7fffffff;      // ragged tail: stages nhs - 2, nhs - 1 hold dropped pieces
   auto step = [&](auto cs_c, auto first_c, auto nw_c, auto ld_c, auto is_c, int hs_issue) __attribute__((always_inline)) {
     constexpr int cs = decltype(cs_c)::value, ns = cs ^ 1;
     constexpr bool first = decltype(first_c)::value;
     constexpr int NW = decltype(nw_c)::value;
     constexpr bool LD = decltype(ld_c)::value, IS = decltype(is_c)::value;
     const int sa = soff_a(hs_issue), sb = soff_b(hs_issue);
-    // own pieces of the next step have landed.  The last slab of a reduction that is not a multiple of 64 deep ends in k-rows past
-    // the descriptor: pieces made of such rows only are answered without going to memory and leave the count early, so from the
-    // step that counts them on the slab waits for EVERYTHING (gemm.hip, gemm_bf16_w4p issue_piece: every counted request a real one)
-    if (step_no >= drain_from) wait_vm<0>();
-    else wait_vm<NW>();
-    ++step_no;
+    wait_vm<NW>();                                // own pieces of the next step have landed
     __builtin_amdgcn_s_barrier();                 // ... and everybody's; the stage of the previous step is free
     const char* tnx = smem + b_next * PP_STAGE;
 #pragma unroll

@@ -1,9 +1,9 @@
-"""Two processes share the card: the condition under which round 4 found an intermittent garbage tile in the persistent GEMMs
-(tools/finite_hunt.py: a counted `s_waitcnt vmcnt(N)` assumed that requests answered without going to memory — all 64 lanes
-outside the buffer descriptor: the zero-record descriptor behind the last tile, rows past M of a ragged tile, the stand-in
-stores of a first tile — stay in the count; they leave it at once, and when a second tenant makes the loads slow an older
-LDS-DMA piece is let through unlanded).  Each process repeats the same training step with every kernel output checked for
-non-finite / absurd values and the step's gradients compared across repetitions."""
+"""Two processes share the card: the condition under which round 4 found an intermittent garbage tile in the 4-wave persistent
+GEMM (tools/finite_hunt.py).  Cause: the sixteen stand-in stores in front of a workgroup's first tile were merged into one by the
+compiler, so the counted `s_waitcnt vmcnt(N)` of that tile's first steps was 15 operations too lax and its first fragments were
+read from a stage that need not have landed — harmless while loads are fast, garbage when a second tenant makes them slow
+(the static side of the fix is tests/test_isa_hazards_cpu.py).  Each process repeats the same training step: one with
+every kernel output checked for non-finite / absurd values, one comparing the step's gradients across repetitions."""
 import os
 import subprocess
 import sys

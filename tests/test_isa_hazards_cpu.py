@@ -281,3 +281,25 @@ def test_ping_pong_ring_keeps_its_segment_discipline(pp_kernels):
             assert k < len(body), name
             audited += 1
     assert audited >= 40
+
+
+def test_first_tile_stand_in_stores_are_all_there(w4_kernels):
+    """Round 4's root cause of the intermittent garbage tiles: steps 0-2 of a tile count the previous tile's direct stores among the
+    operations in flight; before a workgroup's FIRST tile dropped stores stand in for them — and as sixteen identical builtin stores
+    they were merged into one by the compiler, so the first tile's first waits were 15 operations too lax (no wait at all) and its
+    first fragments could be read from a stage that had not landed.  They are asm statements now; this counts them: between the
+    prologue's barrier and the first step's barrier of every specialised 4-wave instantiation sit exactly as many 16-byte buffer
+    stores as the budget of step 0 assumes beyond its 16 LDS-DMA pieces."""
+    kernels, _ = w4_kernels
+    seen = 0
+    for name, body in kernels.items():
+        if _specialised(name) is None or "gemm_f8_w4" in name:
+            continue
+        bars = [i for i, t in enumerate(body) if t == "s_barrier"]
+        stores = sum(1 for t in body[bars[0]:bars[1]] if t.startswith("buffer_store_dwordx4"))
+        waits = [t for t in body[bars[0]:bars[1]] if t.startswith("s_waitcnt vmcnt")]
+        assert waits, name
+        budget = int(re.search(r"vmcnt\((\d+)\)", waits[-1]).group(1))          # the wait in front of step 0's barrier
+        assert stores == budget - 16, f"{name}: {stores} stand-in stores in front of step 0, whose budget vmcnt({budget}) counts {budget - 16}"
+        seen += 1
+    assert seen >= 8

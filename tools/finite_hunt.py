@@ -1,7 +1,7 @@
 """Find the first kernel launch of a training step whose output holds a non-finite (or absurdly large) value.  Every function of
 multimodaldiscussiontransformer_amd.ops is wrapped: after the launch, every tensor it returned or was handed as an output is
-checked (device sync per launch: slow, timing changes — run a second copy beside it to keep the contention that triggers the
-intermittent garbage of DESIGN.md "known issue").  GPU box only:  python tools/finite_hunt.py [--reps 30] [--no-sync-check]"""
+checked (device sync per launch: slow, timing changes — run a second copy beside it to keep the contention that made round 3's
+intermittent garbage tiles show: DESIGN.md §4).  GPU box only:  python tools/finite_hunt.py [--reps 30] [--no-sync-check]"""
 import argparse
 import functools
 import os
