@@ -248,6 +248,14 @@ int mdt_vit_patchify(void* stream, int dtype, int I, int C, int HW, int p, const
 /* tokens[i, off + 0] = cls + pos[0]; tokens[i, off + 1 + j] = patches[i*np + j] + pos[1 + j]. */
 int mdt_vit_assemble(void* stream, int dtype, int I, int np, int D, const void* patches, int64_t ldp,
                      const void* cls, const void* pos, void* tokens, int64_t ldt, int64_t seq_stride, int64_t off);
+/* The three steps above as ONE launch for bf16 weights and 16 x 16 patches (a GEMM whose A loader gathers from
+ * pixel_values; replaces HF ViTEmbeddings as invoked at modules/multigraphormer_graph_encoder.py:332-335):
+ * tokens[i, off + 0] = cls + pos[0]; tokens[i, off + 1 + j] = Conv2d(img[i])[:, py, px] + bias + pos[1 + j], j = py*gw + px,
+ * w bf16 [D, C*p*p] with row stride ldw (the Conv2d weight viewed flat), one rounding to bf16 at the end.
+ * MDT_ERR_UNSUPPORTED for other patch sizes or D not a multiple of 128: the caller takes the three-launch route. */
+int mdt_vit_patch_embed(void* stream, int I, int C, int HW, int p, const float* img, const void* w, int64_t ldw,
+                        const void* bias, const void* cls, const void* pos, int D, void* tokens, int64_t ldt,
+                        int64_t seq_stride, int64_t off);
 
 /* Graph node features (modules/graphormer_layers.py:39-50) on the padded [B, T] grid:
  * x[b,0] = graph_token; x[b,1+n] = (node_row[b,n] >= 0 ? src[node_row[b,n]] : 0)

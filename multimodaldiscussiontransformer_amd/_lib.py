@@ -69,6 +69,7 @@ _SIGS = {
     "mdt_bert_embed_rows": ([_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64], _i),
     "mdt_vit_patchify": ([_vp, _i, _i, _i, _i, _i, _vp, _vp, _i64], _i),
     "mdt_vit_assemble": ([_vp, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64], _i),
+    "mdt_vit_patch_embed": ([_vp, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i64], _i),
     "mdt_graph_node_feature": ([_vp, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64], _i),
     "mdt_tanh_fwd": ([_vp, _i, _i64, _vp, _vp], _i),
     "mdt_tanh_bwd": ([_vp, _i, _i64, _vp, _vp, _vp], _i),

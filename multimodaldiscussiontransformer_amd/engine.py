@@ -288,6 +288,7 @@ _LN_BIAS_RIDE = os.environ.get("MDT_LN_BIAS_RIDE", "1") != "0"    # 0: those sum
 # ------------------------------------------------------------------------------------------
 # input gradients against a transposed weight copy
 _NN_DGRAD = os.environ.get("MDT_NN_DGRAD", "0") == "1"     # 1: the big launches read W through a transposed copy (A/B runs)
+PATCH_EMBED_FUSED = os.environ.get("MDT_PATCH_EMBED_FUSED", "1") != "0"   # 0: patch gather, GEMM and assembly as three launches (A/B runs, tests)
 _WT_CACHE: dict = {}
 WEIGHT_EPOCH = 0            # bumped by whoever rewrites weights behind torch's back (optim.FusedAdam.step)
 
@@ -645,12 +646,22 @@ def vit_embeddings(tape: Tape, images, proj_w, proj_b, cls, pos, patch: int) -> 
     D = proj_w.shape[0]
     g_ = images.shape[-1] // patch
     npatch = g_ * g_
-    cols = ops.vit_patchify(images, patch, proj_w.dtype)
     wmat = proj_w.data.view(D, -1)
-    patches = ops.gemm(cols, wmat, bias=proj_b.data)
     tokens = torch.empty(I * (npatch + 1), D, dtype=proj_w.dtype, device=proj_w.device)
-    ops.vit_assemble(patches, cls.data.view(-1), pos.data.view(npatch + 1, D), tokens, I, npatch,
-                     seq_stride=npatch + 1, off=0)
+    # One launch (the GEMM's A loader gathers from the pixels, ops.vit_patch_embed) when nothing downstream needs the gathered
+    # matrix: inference, or a frozen projection (the shipped launch freezes the ViT embeddings).  A trainable projection's
+    # weight gradient contracts over that matrix, so it is made once here and kept.
+    fused = (PATCH_EMBED_FUSED and proj_w.dtype == torch.bfloat16 and patch == 16 and D % 128 == 0
+             and (tape.inference or not (proj_w.requires_grad or proj_b.requires_grad)))
+    cols = patches = None
+    if fused:
+        ops.vit_patch_embed(images, patch, wmat, proj_b.data, cls.data.view(-1), pos.data.view(npatch + 1, D), tokens,
+                            seq_stride=npatch + 1, off=0)
+    else:
+        cols = ops.vit_patchify(images, patch, proj_w.dtype)
+        patches = ops.gemm(cols, wmat, bias=proj_b.data)
+        ops.vit_assemble(patches, cls.data.view(-1), pos.data.view(npatch + 1, D), tokens, I, npatch,
+                         seq_stride=npatch + 1, off=0)
     o = Var(tokens)
 
     def bwd():
@@ -660,7 +671,7 @@ def vit_embeddings(tape: Tape, images, proj_w, proj_b, cls, pos, patch: int) -> 
             return
         gw, gb, gc, gp = tape.pgrad(proj_w), tape.pgrad(proj_b), tape.pgrad(cls), tape.pgrad(pos)
         if gw is not None or gb is not None:
-            dpatch = torch.empty_like(patches)
+            dpatch = torch.empty(I * npatch, D, dtype=g.dtype, device=g.device)
             ops.row_axpby(dpatch, I * npatch, a=g, a_inner=npatch, a_stride=npatch + 1, a_off=1)
             if gw is not None:
                 ops.gemm(dpatch, cols, trans_a=True, trans_b=True, out=gw.view(D, -1), epilogue=ops.EPI_ATOMIC,

@@ -18,7 +18,7 @@ from ._lib import MdtError
 __all__ = [
     "bert_embed_rows",
     "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "attention_mean_probs", "graph_attn_bias",
-    "row_axpby", "row_scatter_add", "bert_embed_sum", "vit_patchify", "vit_assemble", "graph_node_feature",
+    "row_axpby", "row_scatter_add", "bert_embed_sum", "vit_patchify", "vit_assemble", "vit_patch_embed", "graph_node_feature",
     "tanh_fwd", "tanh_bwd", "node_ce", "contrastive_loss", "fp8_quantize", "fp8_scale_update", "gemm_fp8", "cast", "transpose2d", "dropout", "dropout_mask",
     "EPI_BIAS", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_ACCUM", "EPI_ATOMIC", "EPI_DROPOUT", "EPI_AUX_GRAD", "EPI_MULAUX", "EPI_ASUM",
 ]
@@ -292,6 +292,16 @@ def vit_patchify(images, patch, dtype):
 def vit_assemble(patches, cls, pos, tokens, I, npatch, *, seq_stride, off):
     check(lib.mdt_vit_assemble(stream(), dt(patches), I, npatch, patches.shape[1], ptr(patches), _2d(patches), ptr(cls),
                                ptr(pos), ptr(tokens), _2d(tokens), seq_stride, off), "mdt_vit_assemble")
+    return tokens
+
+
+def vit_patch_embed(images, patch, wmat, bias, cls, pos, tokens, *, seq_stride, off):
+    """Patch gather + projection + bias + [CLS] + position add in one launch (bf16 weights, 16 x 16 patches); raises
+    ``MdtUnsupported`` for other shapes — the caller then takes vit_patchify + gemm + vit_assemble."""
+    I, Cc, HW, _ = images.shape
+    assert images.dtype == torch.float32 and images.is_contiguous() and wmat.dtype == torch.bfloat16 and wmat.stride(1) == 1
+    check(lib.mdt_vit_patch_embed(stream(), I, Cc, HW, patch, ptr(images), ptr(wmat), wmat.stride(0), ptr(bias), ptr(cls), ptr(pos),
+                                  wmat.shape[0], ptr(tokens), _2d(tokens), seq_stride, off), "mdt_vit_patch_embed")
     return tokens
 
 

@@ -536,6 +536,54 @@ def test_row_ops(ops, dtype):
     torch.testing.assert_close(table.cpu(), ref, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("I,HW,D,nb", [(3, 224, 768, 0), (5, 64, 256, 4), (1, 32, 128, 2)])
+def test_vit_patch_embed_in_one_launch(ops, I, HW, D, nb):
+    """Conv2d(3, D, k = s = 16) + bias + [CLS] + position add with the GEMM's A loader gathering from pixel_values
+    (csrc/patch_embed.hip) against (a) F.conv2d in fp64 on the bf16-rounded pixels and weights — the one rounding of the result
+    to bf16 allows half a bf16 ulp (2^-9 relative) plus the fp32 accumulation order; (b) the three-launch route
+    (vit_patchify + gemm + vit_assemble), which rounds twice (the patch value, then the sum): within an ulp of the larger of the two.  M = I * (HW / 16)^2 is not a multiple
+    of the 128-row tile in any case; rows in front of the image tokens (bottleneck slots, off = nb) stay untouched."""
+    bf = torch.bfloat16
+    p, C = 16, 3
+    gw = HW // p
+    npatch = gw * gw
+    img = rnd(I, C, HW, HW, seed=21, scale=2.0)
+    w = rnd(D, C, p, p, seed=22, scale=0.05).to(bf)
+    b, cls, pos = rnd(D, seed=23, scale=0.3).to(bf), rnd(D, seed=24).to(bf), rnd(npatch + 1, D, seed=25, scale=0.5).to(bf)
+    S = nb + npatch + 1
+    tok = torch.full((I * S, D), 7.0, dtype=bf).cuda()
+    ops.vit_patch_embed(dev(img), p, dev(w).view(D, -1), dev(b), dev(cls), dev(pos), tok, seq_stride=S, off=nb)
+    got = tok.float().cpu().view(I, S, D)
+    conv = F.conv2d(img.to(bf).double(), w.double(), b.double(), stride=p).flatten(2).transpose(1, 2)      # [I, np, D]
+    ref = torch.cat([cls.double().expand(I, 1, D), conv], 1) + pos.double()[None]
+    err = (got[:, nb:].double() - ref).abs()
+    tol = ref.abs() * 2.0 ** -8 + 2e-4                 # half an ulp of the result + accumulation order + margin
+    assert bool((err <= tol).all()), (float(err.max()), float((err / tol).max()))
+    if nb:
+        assert float((got[:, :nb] - 7.0).abs().max()) == 0.0
+    # the three-launch route on the same inputs
+    cols = ops.vit_patchify(dev(img), p, bf)
+    patches = ops.gemm(cols, dev(w).view(D, -1), bias=dev(b))
+    tok3 = torch.full((I * S, D), 7.0, dtype=bf).cuda()
+    ops.vit_assemble(patches, dev(cls), dev(pos), tok3, I, npatch, seq_stride=S, off=nb)
+    d3 = (tok.float() - tok3.float()).abs().cpu().view(I, S, D)[:, nb:].double()
+    mag = torch.cat([cls.double().abs().expand(I, 1, D), conv.abs()], 1) + pos.double().abs()[None]     # the first rounding is of the patch value, not of the sum
+    assert bool((d3 <= mag * 2.0 ** -7 + 1e-3).all()), float(d3.max())
+    # and it is closer to the exact result than the route that rounds twice (mean error)
+    e3 = (tok3.float().cpu().view(I, S, D)[:, nb:].double() - ref).abs().mean()
+    assert float(err.mean()) <= float(e3) * 1.02, (float(err.mean()), float(e3))
+
+
+def test_vit_patch_embed_refuses_what_it_has_no_kernel_for(ops):
+    """14 x 14 patches (ViT-L/14) take the three-launch route: the entry point says so with MDT_ERR_UNSUPPORTED, not with garbage."""
+    bf = torch.bfloat16
+    img = rnd(1, 3, 28, 28, seed=1)
+    w = rnd(128, 3 * 14 * 14 + 4, seed=2).to(bf)[:, :588]
+    tok = torch.zeros(5, 128, dtype=bf).cuda()
+    with pytest.raises(L.MdtUnsupported):
+        ops.vit_patch_embed(dev(img), 14, dev(w), dev(rnd(128).to(bf)), dev(rnd(128).to(bf)), dev(rnd(5, 128).to(bf)), tok, seq_stride=5, off=0)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_embeddings_and_features(ops, dtype):
     D, L, M, V = 128, 6, 5, 50

@@ -274,6 +274,57 @@ def test_ragged_tokens_equal_padded_tokens_fp32():
         torch.testing.assert_close(g1[n], g0[n], atol=2e-5 * max(1.0, float(g0[n].abs().max())), rtol=1e-4, msg=n)
 
 
+def test_patch_embedding_takes_one_launch_when_nothing_needs_the_gathered_matrix(monkeypatch):
+    """SURVEY K8 in the model: a bf16 model whose ViT patch projection is frozen (the shipped launch: --freeze_initial_encoders)
+    or that runs without a tape (validation) embeds its patches with ops.vit_patch_embed; a trainable projection keeps the
+    three-launch route (its weight gradient contracts over the gathered matrix).  Same logits either way up to the one bf16
+    rounding the fused kernel saves; gradients of a frozen-projection step likewise."""
+    from multimodaldiscussiontransformer_amd import engine, ops
+    from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
+    from multimodaldiscussiontransformer_amd.data.packer import pack_batch
+    from multimodaldiscussiontransformer_amd.models import GraphormerModel
+    hp = cases.tiny_hparams("A")
+    trees = cases.tiny_trees("A", hp)
+    calls = []
+    real = ops.vit_patch_embed
+    monkeypatch.setattr(ops, "vit_patch_embed", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(engine, "PATCH_EMBED_FUSED", fused)
+        model = GraphormerModel.build_model(model_args(hp), task=None)
+        fill_hash_weights(model)
+        model = model.cuda().bfloat16().eval()
+        ge = model.encoder.graph_encoder
+        if ge.vit_model.embeddings.patch_embeddings.projection.weight.shape[0] % 128:
+            pytest.skip("tiny ViT width is not a multiple of the 128-column tile")
+        pb = pack_batch(trees, 5)
+        crit = GraphPredictionNodeCrossEntropy(None, positive_weight=1.5, negative_weight=1.0)
+        n0 = len(calls)
+        loss, _, _ = crit(model, {"nsamples": len(trees), "net_input": {"batched_data": pb.batched_data}})
+        loss.backward()
+        trainable_calls = len(calls) - n0
+        for q in ge.vit_model.embeddings.patch_embeddings.parameters():
+            q.requires_grad_(False)
+        model.zero_grad()
+        n0 = len(calls)
+        loss, _, _ = crit(model, {"nsamples": len(trees), "net_input": {"batched_data": pb.batched_data}})
+        loss.backward()
+        frozen_calls = len(calls) - n0
+        n0 = len(calls)
+        with torch.no_grad():
+            logits, _ = model(pb.batched_data)
+        res[fused] = (float(loss.detach()), logits.float().cpu(), trainable_calls, frozen_calls, len(calls) - n0,
+                      {n: q.grad.float().cpu() for n, q in model.named_parameters() if q.grad is not None})
+    assert res[False][2:5] == (0, 0, 0) and res[True][2] == 0 and res[True][3] >= 1 and res[True][4] >= 1, (res[False][2:5], res[True][2:5])
+    assert abs(res[True][0] - res[False][0]) < 2e-2 * max(1.0, abs(res[False][0]))
+    torch.testing.assert_close(res[True][1], res[False][1], atol=3e-2, rtol=3e-2)
+    g0, g1 = res[False][5], res[True][5]
+    assert set(g0) == set(g1)
+    num = sum(float((g1[n].double() - g0[n].double()).pow(2).sum()) for n in g0)
+    den = sum(float(g0[n].double().pow(2).sum()) for n in g0)
+    assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
+
+
 @pytest.mark.parametrize("kind", ["A", "B"])
 def test_pruned_last_fusion_layer_equals_full_fp32(kind):
     """The logits path computes only bottleneck token 0 and [CLS] of every comment in the LAST fusion layer (the
