@@ -241,6 +241,14 @@ int mdt_bert_embed_sum(void* stream, int dtype, int64_t M, int L, const int32_t*
 int mdt_bert_embed_rows(void* stream, int dtype, int64_t rows, const int32_t* ids, const int32_t* types,
                         const int32_t* pos_ids, const void* word, const void* pos, const void* type, int D,
                         void* out, int64_t ldo);
+/* The same sum followed by its LayerNorm in ONE pass (HF BertEmbeddings incl. its LayerNorm, as run by the truncated
+ * BertModel at modules/multigraphormer_graph_encoder.py:325-329): xs[r,:] = T(word + type + pos) exactly as mdt_bert_embed_rows
+ * leaves it (xs may be NULL: nobody will read the sum), y[r,:] = LayerNorm(xs[r,:]) * gamma + beta, mean / rstd fp32[rows] (may be
+ * NULL) — bit-identical to mdt_bert_embed_rows + mdt_layernorm_fwd. */
+int mdt_bert_embed_ln_rows(void* stream, int dtype, int64_t rows, const int32_t* ids, const int32_t* types,
+                           const int32_t* pos_ids, const void* word, const void* pos, const void* type, int D,
+                           const void* gamma, const void* beta, float eps, void* xs, int64_t ldxs, void* y, int64_t ldy,
+                           float* mean, float* rstd);
 
 /* ViT patch gather (Conv2d k=s=p is a pure re-index, modules/multigraphormer_graph_encoder.py:333):
  * cols[(i*np + py*gw + px), c*p*p + dy*p + dx] = img[i, c, py*p+dy, px*p+dx]  (img fp32 → T). */

@@ -67,6 +67,7 @@ _SIGS = {
     "mdt_row_scatter_add_f32": ([_vp, _i, _i64, _i, _vp, _i64, _vp, _vp, _i64, _i64, _i64], _i),
     "mdt_bert_embed_sum": ([_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i64], _i),
     "mdt_bert_embed_rows": ([_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64], _i),
+    "mdt_bert_embed_ln_rows": ([_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _i64, _vp, _i64, _vp, _vp], _i),
     "mdt_vit_patchify": ([_vp, _i, _i, _i, _i, _i, _vp, _vp, _i64], _i),
     "mdt_vit_assemble": ([_vp, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64], _i),
     "mdt_vit_patch_embed": ([_vp, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i64], _i),

@@ -153,6 +153,88 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int D,
   }
 }
 
+// BERT embeddings and their LayerNorm in one pass (HF BertEmbeddings as run by the truncated BertModel,
+// modules/multigraphormer_graph_encoder.py:325-329): x = T(word[ids] + type[types] + pos[pos_ids]) — rounded to the storage type
+// exactly as mdt_bert_embed_rows leaves it — then y = LayerNorm(x).  The summed row never makes the round trip through HBM between
+// the two; it is written out (xs) only when a backward pass will read it.  One wave per row, the next row's three gathers in flight.
+template <typename T, int NV, typename V = Vec<T>>
+__global__ __launch_bounds__(256) void bert_embed_ln_rows_kernel(int64_t rows, int D, const int32_t* __restrict__ ids,
+                                                                 const int32_t* __restrict__ types, const int32_t* __restrict__ pos_ids,
+                                                                 const T* __restrict__ word, const T* __restrict__ pos,
+                                                                 const T* __restrict__ typ, const T* __restrict__ gamma,
+                                                                 const T* __restrict__ beta, float eps, T* __restrict__ xs, int64_t ldxs,
+                                                                 T* __restrict__ y, int64_t ldy, float* __restrict__ mean,
+                                                                 float* __restrict__ rstd) {
+  constexpr int VN = V::N;
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  V gv[NV], bv[NV], wv[NV], pv[NV], tv[NV], wn[NV], pn[NV], tn[NV];
+  auto request = [&](int64_t r, V* w_, V* p_, V* t_) {
+    const int64_t wi = ids[r], pi = pos_ids[r], ti = types[r];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * VN;
+      if (c < D) {
+        w_[i] = *(const V*)(word + wi * D + c);
+        p_[i] = *(const V*)(pos + pi * D + c);
+        t_[i] = *(const V*)(typ + ti * D + c);
+      }
+    }
+  };
+  request(row, wv, pv, tv);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * VN;
+    if (c < D) { gv[i] = *(const V*)(gamma + c); bv[i] = *(const V*)(beta + c); }
+  }
+  for (;;) {
+    const int64_t next = row + nwaves;
+    if (next < rows) request(next, wn, pn, tn);
+    V xv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * VN;
+      if (c < D) {
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+          xv[i].set(j, wv[i].get(j) + tv[i].get(j) + pv[i].get(j));      // the order and the rounding of bert_embed_rows_kernel
+          s += xv[i].get(j);
+        }
+        if (xs) *(V*)(xs + row * ldxs + c) = xv[i];
+      }
+    }
+    const float mu = wave_sum_dpp(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * VN;
+      if (c < D) {
+#pragma unroll
+        for (int j = 0; j < VN; ++j) { const float d = xv[i].get(j) - mu; q += d * d; }
+      }
+    }
+    const float rs = rsqrtf(wave_sum_dpp(q) / (float)D + eps);
+    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * VN;
+      if (c < D) {
+        V o;
+#pragma unroll
+        for (int j = 0; j < VN; ++j) o.set(j, (xv[i].get(j) - mu) * rs * gv[i].get(j) + bv[i].get(j));
+        *(V*)(y + row * ldy + c) = o;
+      }
+    }
+    if (next >= rows) break;
+    row = next;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { wv[i] = wn[i]; pv[i] = pn[i]; tv[i] = tn[i]; }
+  }
+}
+
 // Backward: each wave walks rows_per_wave consecutive rows (the next row's x / dy / residual-gradient vectors are
 // requested before the current row is reduced), keeps per-lane partial dgamma / dbeta / column sums in registers,
 // the block combines them through ONE [4 waves][row] LDS buffer used three times (16 KiB at D = 768: the 48 KiB of
@@ -411,6 +493,46 @@ extern "C" int mdt_layernorm_fwd_q8(void* stream, int dtype, int64_t rows, int D
   if (int e = ln_check(dtype, D, ldx, ldy, x, y)) return e;
   MDT_CHECK_ARG((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "layernorm_fwd_q8: gamma/beta must be 16-byte aligned");
   return ln_fwd_dispatch<bf16_t>((hipStream_t)stream, rows, D, x, ldx, gamma, beta, eps, y, ldy, mean, rstd, q8_out, ld_q8, q8_format, q8_scale, q8_amax);
+}
+
+template <typename T>
+static int embed_ln_dispatch(hipStream_t st, int64_t rows, int D, const int32_t* ids, const int32_t* types, const int32_t* pos_ids,
+                             const void* word, const void* pos, const void* typ, const void* gamma, const void* beta, float eps,
+                             void* xs, int64_t ldxs, void* y, int64_t ldy, float* mean, float* rstd) {
+  constexpr int VN = Vec<T>::N;
+  const int nv = (D + 64 * VN - 1) / (64 * VN);
+  const int64_t wgs = (rows + 3) / 4;
+  const unsigned grid = (unsigned)(wgs < 2048 ? wgs : 2048);
+#define EL_(NV_, V_) hipLaunchKernelGGL((bert_embed_ln_rows_kernel<T, NV_, V_>), grid, 256, 0, st, rows, D, ids, types, pos_ids, (const T*)word, \
+                                        (const T*)pos, (const T*)typ, (const T*)gamma, (const T*)beta, eps, (T*)xs, ldxs, (T*)y, ldy, mean, rstd)
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    if (D == 768) { EL_(3, VecH<T>); return check_launch("bert_embed_ln_rows"); }
+  }
+  switch (nv) {
+    case 1: EL_(1, Vec<T>); break;
+    case 2: EL_(2, Vec<T>); break;
+    case 3: EL_(3, Vec<T>); break;
+    case 4: EL_(4, Vec<T>); break;
+    case 6: EL_(6, Vec<T>); break;
+    case 8: EL_(8, Vec<T>); break;
+    default: MDT_UNSUPPORTED("bert_embed_ln_rows: D=%d not supported (vectors per lane %d)", D, nv);
+  }
+#undef EL_
+  return check_launch("bert_embed_ln_rows");
+}
+
+extern "C" int mdt_bert_embed_ln_rows(void* stream, int dtype, int64_t rows, const int32_t* ids, const int32_t* types,
+                                      const int32_t* pos_ids, const void* word, const void* pos, const void* type, int D,
+                                      const void* gamma, const void* beta, float eps, void* xs, int64_t ldxs, void* y, int64_t ldy,
+                                      float* mean, float* rstd) {
+  if (rows == 0) return MDT_OK;
+  MDT_CHECK_ARG(ids && types && pos_ids && word && pos && type && gamma && beta && y, "bert_embed_ln_rows: null pointer");
+  if (int e = ln_check(dtype, D, xs ? ldxs : ldy, ldy, xs ? xs : y, y)) return e;
+  MDT_CHECK_ARG((((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)word | (uintptr_t)pos | (uintptr_t)type) & 15) == 0,
+                "bert_embed_ln_rows: tables, gamma and beta must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == MDT_F32 ? embed_ln_dispatch<float>(st, rows, D, ids, types, pos_ids, word, pos, type, gamma, beta, eps, xs, ldxs, y, ldy, mean, rstd)
+                          : embed_ln_dispatch<bf16_t>(st, rows, D, ids, types, pos_ids, word, pos, type, gamma, beta, eps, xs, ldxs, y, ldy, mean, rstd);
 }
 
 extern "C" int mdt_layernorm_bwd(void* stream, int dtype, int64_t rows, int D, const void* dy, int64_t lddy,

@@ -288,6 +288,7 @@ _LN_BIAS_RIDE = os.environ.get("MDT_LN_BIAS_RIDE", "1") != "0"    # 0: those sum
 # ------------------------------------------------------------------------------------------
 # input gradients against a transposed weight copy
 _NN_DGRAD = os.environ.get("MDT_NN_DGRAD", "0") == "1"     # 1: the big launches read W through a transposed copy (A/B runs)
+EMBED_LN_FUSED = os.environ.get("MDT_EMBED_LN_FUSED", "1") != "0"         # 0: embedding sum and its LayerNorm as two launches (A/B runs, tests)
 PATCH_EMBED_FUSED = os.environ.get("MDT_PATCH_EMBED_FUSED", "1") != "0"   # 0: patch gather, GEMM and assembly as three launches (A/B runs, tests)
 _WT_CACHE: dict = {}
 WEIGHT_EPOCH = 0            # bumped by whoever rewrites weights behind torch's back (optim.FusedAdam.step)
@@ -611,6 +612,21 @@ def bert_embeddings(tape: Tape, ids, types, word, pos, typ) -> Var:
     return o
 
 
+def _embed_rows_grads(tape: Tape, g, rows, ids, types, pos_ids, word, pos, typ):
+    gw, gp, gt = tape.pgrad(word), tape.pgrad(pos), tape.pgrad(typ)
+    D = word.shape[1]
+    if gw is not None:
+        ops.row_scatter_add(gw, ids, g, rows)
+    if gp is not None:
+        ops.row_scatter_add(gp, pos_ids, g, rows)
+    if gt is not None:
+        assert typ.shape[0] == 2, "token-type gradient is implemented for type_vocab_size == 2"
+        tot = ops.colsum(g)
+        one = ops.colsum(g, row_weight=types)
+        ops.row_axpby(gt, 1, d_off=1, a=one.view(1, D), accumulate=True)
+        ops.row_axpby(gt, 1, d_off=0, a=tot.view(1, D), b=one.view(1, D), beta=-1.0, accumulate=True)
+
+
 def bert_embeddings_rows(tape: Tape, ids, types, pos_ids, word, pos, typ) -> Var:
     """Ragged form of ``bert_embeddings``: one row per VALID token (ids / types / pos_ids i32[rows])."""
     rows = ids.numel()
@@ -624,17 +640,27 @@ def bert_embeddings_rows(tape: Tape, ids, types, pos_ids, word, pos, typ) -> Var
         o.grad = None
         if g is None:
             return
-        gw, gp, gt = tape.pgrad(word), tape.pgrad(pos), tape.pgrad(typ)
-        if gw is not None:
-            ops.row_scatter_add(gw, ids, g, rows)
-        if gp is not None:
-            ops.row_scatter_add(gp, pos_ids, g, rows)
-        if gt is not None:
-            assert typ.shape[0] == 2, "token-type gradient is implemented for type_vocab_size == 2"
-            tot = ops.colsum(g)
-            one = ops.colsum(g, row_weight=types)
-            ops.row_axpby(gt, 1, d_off=1, a=one.view(1, D), accumulate=True)
-            ops.row_axpby(gt, 1, d_off=0, a=tot.view(1, D), b=one.view(1, D), beta=-1.0, accumulate=True)
+        _embed_rows_grads(tape, g, rows, ids, types, pos_ids, word, pos, typ)
+
+    tape.record(bwd)
+    return o
+
+
+def bert_embeddings_ln_rows(tape: Tape, ids, types, pos_ids, word, pos, typ, w, b, eps: float) -> Var:
+    """``layernorm(bert_embeddings_rows(...))`` in one pass (ops.bert_embed_ln_rows): same bits; the summed rows are
+    written out only when a backward pass will read them."""
+    rows = ids.numel()
+    y, mean, rstd, xs = ops.bert_embed_ln_rows(ids, types, pos_ids, word.data, pos.data, typ.data, w.data, b.data, eps,
+                                               keep_sum=not tape.inference)
+    o = Var(y)
+
+    def bwd():
+        g = o.grad
+        o.grad = None
+        if g is None:
+            return
+        dx = _ln_bwd(tape, g, xs, w, b, mean, rstd)
+        _embed_rows_grads(tape, dx, rows, ids, types, pos_ids, word, pos, typ)
 
     tape.record(bwd)
     return o

@@ -334,12 +334,18 @@ class MultiGraphormerGraphEncoder(nn.Module):
         e = tm.embeddings
         if ix["ragged"]:
             rt = get_ragged(pb)
-            emb = E.bert_embeddings_rows(tape, rt.ids, rt.types, rt.pos, e.word_embeddings.weight,
-                                         e.position_embeddings.weight, e.token_type_embeddings.weight)
+            if E.EMBED_LN_FUSED:
+                normed = E.bert_embeddings_ln_rows(tape, rt.ids, rt.types, rt.pos, e.word_embeddings.weight, e.position_embeddings.weight,
+                                                   e.token_type_embeddings.weight, e.LayerNorm.weight, e.LayerNorm.bias, tm.eps)
+            else:
+                emb = E.bert_embeddings_rows(tape, rt.ids, rt.types, rt.pos, e.word_embeddings.weight,
+                                             e.position_embeddings.weight, e.token_type_embeddings.weight)
+                normed = E.layernorm(tape, emb, e.LayerNorm.weight, e.LayerNorm.bias, tm.eps)
         else:
             emb = E.bert_embeddings(tape, pb.ids, pb.types, e.word_embeddings.weight, e.position_embeddings.weight,
                                     e.token_type_embeddings.weight)
-        text = E.dropout(tape, E.layernorm(tape, emb, e.LayerNorm.weight, e.LayerNorm.bias, tm.eps), p_emb)
+            normed = E.layernorm(tape, emb, e.LayerNorm.weight, e.LayerNorm.bias, tm.eps)
+        text = E.dropout(tape, normed, p_emb)
         spec0 = E.AttnSpec(nseq=M, H=tm.heads, **ix["spec_pre"])
         for layer in tm.encoder.layer:
             text = E.transformer_block(tape, text, layer.block_params(), spec0, pre_ln=False, eps=tm.eps,

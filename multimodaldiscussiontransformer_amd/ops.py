@@ -18,7 +18,7 @@ from ._lib import MdtError
 __all__ = [
     "bert_embed_rows",
     "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "attention_mean_probs", "graph_attn_bias",
-    "row_axpby", "row_scatter_add", "bert_embed_sum", "vit_patchify", "vit_assemble", "vit_patch_embed", "graph_node_feature",
+    "row_axpby", "row_scatter_add", "bert_embed_sum", "bert_embed_ln_rows", "vit_patchify", "vit_assemble", "vit_patch_embed", "graph_node_feature",
     "tanh_fwd", "tanh_bwd", "node_ce", "contrastive_loss", "fp8_quantize", "fp8_scale_update", "gemm_fp8", "cast", "transpose2d", "dropout", "dropout_mask",
     "EPI_BIAS", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_ACCUM", "EPI_ATOMIC", "EPI_DROPOUT", "EPI_AUX_GRAD", "EPI_MULAUX", "EPI_ASUM",
 ]
@@ -277,6 +277,22 @@ def bert_embed_rows(ids, types, pos_ids, word, pos, type_emb, out):
     check(lib.mdt_bert_embed_rows(stream(), dt(word), rows, ptr(ids), ptr(types), ptr(pos_ids), ptr(word), ptr(pos),
                                   ptr(type_emb), word.shape[1], ptr(out), _2d(out)), "mdt_bert_embed_rows")
     return out
+
+
+def bert_embed_ln_rows(ids, types, pos_ids, word, pos, type_emb, gamma, beta, eps, *, keep_sum=True):
+    """word + type + position rows and their LayerNorm in one pass → (y, mean, rstd, summed rows or None)."""
+    rows = ids.numel()
+    for t in (ids, types, pos_ids):
+        assert t.dtype == torch.int32 and t.is_contiguous() and t.numel() == rows
+    D = word.shape[1]
+    y = torch.empty(rows, D, dtype=word.dtype, device=word.device)
+    xs = torch.empty(rows, D, dtype=word.dtype, device=word.device) if keep_sum else None
+    mean = torch.empty(rows, dtype=torch.float32, device=word.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=word.device)
+    check(lib.mdt_bert_embed_ln_rows(stream(), dt(word), rows, ptr(ids), ptr(types), ptr(pos_ids), ptr(word), ptr(pos), ptr(type_emb), D,
+                                     ptr(gamma), ptr(beta), float(eps), ptr(xs), _2d(xs) if xs is not None else 0, ptr(y), _2d(y),
+                                     ptr(mean), ptr(rstd)), "mdt_bert_embed_ln_rows")
+    return y, mean, rstd, xs
 
 
 def vit_patchify(images, patch, dtype):

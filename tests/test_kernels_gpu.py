@@ -536,6 +536,32 @@ def test_row_ops(ops, dtype):
     torch.testing.assert_close(table.cpu(), ref, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,D", [(1, 128), (37, 768), (4099, 768), (260, 1024)])
+def test_bert_embeddings_and_their_layernorm_in_one_pass(ops, dtype, rows, D):
+    """mdt_bert_embed_ln_rows = mdt_bert_embed_rows + mdt_layernorm_fwd, bit for bit (output, statistics and the
+    summed rows backward reads), and against the fp32 formula on the CPU; without the summed rows (inference) the same output."""
+    V, P = 211, 40
+    g = torch.Generator().manual_seed(rows + D)
+    ids = torch.randint(0, V, (rows,), generator=g, dtype=torch.int32)
+    types = torch.randint(0, 2, (rows,), generator=g, dtype=torch.int32)
+    pos_ids = torch.randint(0, P, (rows,), generator=g, dtype=torch.int32)
+    word, pos, typ = rnd(V, D, seed=1).to(dtype), rnd(P, D, seed=2, scale=0.5).to(dtype), rnd(2, D, seed=3, scale=0.2).to(dtype)
+    gamma, beta = (1 + rnd(D, seed=4, scale=0.2)).to(dtype), rnd(D, seed=5, scale=0.1).to(dtype)
+    args = (dev(ids), dev(types), dev(pos_ids), dev(word), dev(pos), dev(typ))
+    y, mean, rstd, xs = ops.bert_embed_ln_rows(*args, dev(gamma), dev(beta), 1e-12)
+    two = torch.empty(rows, D, dtype=dtype).cuda()
+    ops.bert_embed_rows(*args, two)
+    y2, mean2, rstd2 = ops.layernorm_fwd(two, dev(gamma), dev(beta), 1e-12)
+    assert torch.equal(xs, two) and torch.equal(y, y2) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    y3, _, _, none = ops.bert_embed_ln_rows(*args, dev(gamma), dev(beta), 1e-12, keep_sum=False)
+    assert none is None and torch.equal(y3, y)
+    x = (word.float()[ids.long()] + typ.float()[types.long()] + pos.float()[pos_ids.long()]).to(dtype).float()
+    ref = F.layer_norm(x, (D,), gamma.float(), beta.float(), 1e-12)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    torch.testing.assert_close(y.float().cpu(), ref, atol=tol, rtol=tol)
+
+
 @pytest.mark.parametrize("I,HW,D,nb", [(3, 224, 768, 0), (5, 64, 256, 4), (1, 32, 128, 2)])
 def test_vit_patch_embed_in_one_launch(ops, I, HW, D, nb):
     """Conv2d(3, D, k = s = 16) + bias + [CLS] + position add with the GEMM's A loader gathering from pixel_values

@@ -274,6 +274,41 @@ def test_ragged_tokens_equal_padded_tokens_fp32():
         torch.testing.assert_close(g1[n], g0[n], atol=2e-5 * max(1.0, float(g0[n].abs().max())), rtol=1e-4, msg=n)
 
 
+@pytest.mark.parametrize("half", [False, True])
+def test_embeddings_with_their_layernorm_in_one_pass_change_no_bit(monkeypatch, half):
+    """SURVEY K9 in the model (ragged token layout): the fused embedding + LayerNorm pass gives the loss and the logits of the two-launch route bit for bit, in fp32 and in bf16,
+    and its gradients up to the order of fp32 atomics."""
+    from multimodaldiscussiontransformer_amd import engine
+    from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
+    from multimodaldiscussiontransformer_amd.data.packer import pack_batch
+    from multimodaldiscussiontransformer_amd.models import GraphormerModel
+    hp = cases.tiny_hparams("A")
+    trees = cases.tiny_trees("A", hp)
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(engine, "EMBED_LN_FUSED", fused)
+        model = GraphormerModel.build_model(model_args(hp), task=None)
+        fill_hash_weights(model)
+        model = model.cuda()
+        model = (model.bfloat16() if half else model).eval()
+        ge = model.encoder.graph_encoder
+        ge.ragged_tokens = True
+        ge.two_streams = False                    # one stream: the atomics of the embedding scatter in one order
+        pb = pack_batch(trees, 5)
+        crit = GraphPredictionNodeCrossEntropy(None, positive_weight=1.5, negative_weight=1.0)
+        loss, _, _ = crit(model, {"nsamples": len(trees), "net_input": {"batched_data": pb.batched_data}})
+        loss.backward()
+        with torch.no_grad():
+            logits, _ = model(pb.batched_data)
+        res[fused] = (float(loss.detach()), logits.float().cpu(), {n: q.grad.float().cpu() for n, q in model.named_parameters() if q.grad is not None})
+    assert res[True][0] == res[False][0] and torch.equal(res[True][1], res[False][1])
+    assert set(res[True][2]) == set(res[False][2])
+    for n, g0 in res[False][2].items():
+        g1 = res[True][2][n]
+        # fp32 atomics (embedding scatter, LayerNorm column sums, split-K slabs) add in whatever order they finish
+        torch.testing.assert_close(g1, g0, atol=(2e-5 if not half else 2e-3) * max(1.0, float(g0.abs().max())), rtol=1e-4 if not half else 1e-2, msg=n)
+
+
 def test_patch_embedding_takes_one_launch_when_nothing_needs_the_gathered_matrix(monkeypatch):
     """SURVEY K8 in the model: a bf16 model whose ViT patch projection is frozen (the shipped launch: --freeze_initial_encoders)
     or that runs without a tape (validation) embeds its patches with ops.vit_patch_embed; a trainable projection keeps the
