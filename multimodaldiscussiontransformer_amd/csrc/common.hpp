@@ -56,6 +56,8 @@ struct Switches {
   bool attn_no_w8;           // MDT_ATTN_NO_W8
   bool attn_exact_delta;     // MDT_ATTN_EXACT_DELTA (default 1: one-pass backward of rows <= 96 tokens sums delta = sum P o dP itself; 0: rowsum(dO o O) from the bf16 output)
   int attn_onepass;          // MDT_ATTN_ONEPASS   (0: two-pass backward kernels only; default: one-pass wherever its dS image fits LDS)
+  bool ln_generic;           // MDT_LN_GENERIC     (default 0; 1: bf16 rows of 768 take the generic LayerNorm backward kernel — tests, A/B runs)
+  int ln_bwd_wgs;            // MDT_LN_BWD_WGS     (workgroups a LayerNorm backward launch aims for; tuning)
 };
 const Switches& switches();
 

@@ -59,6 +59,8 @@ static void read_switches() {
   g_sw.attn_no_occ4 = flag("MDT_ATTN_NO_OCC4");
   g_sw.attn_no_w8 = flag("MDT_ATTN_NO_W8");
   g_sw.attn_onepass = num("MDT_ATTN_ONEPASS", -1);
+  g_sw.ln_generic = flag("MDT_LN_GENERIC");
+  g_sw.ln_bwd_wgs = num("MDT_LN_BWD_WGS", 2048);
   g_sw_valid = true;
 }
 

@@ -3,6 +3,7 @@
 // HBM-bound: algorithmic bytes = rows * D * sizeof(T) * 2 (fwd), * 3 (+ residual 4) (bwd).
 // Replaces fairseq LayerNorm / HF nn.LayerNorm (modules/graphormer_graph_encoder_layer.py:
 // 127-130,138-141; modules/multigraphormer_graph_encoder.py:400-403; HF BertLayer/ViTLayer).
+#include <algorithm>
 #include <type_traits>
 
 #include "common.hpp"
@@ -362,6 +363,137 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int D,
   }
 }
 
+// The backward kernel for bf16 rows of 256 * NV elements (768: every LayerNorm of mDT-base; 1024: mDT-large) with its addresses in SCALAR registers: a wave owns whole
+// rows, so a row's byte offset is wave-uniform — each tensor is a buffer descriptor based at the wave's first row, the row offset
+// goes into the instruction's SGPR operand, the vector's place in the row into its 12-bit immediate (0 / 512 / 1024), and ONE VGPR
+// (lane * 8) serves every load and store of the kernel.  Same arithmetic in the same order as layernorm_bwd_kernel<bf16_t, 3, ...,
+// VecH>: what changes is the register budget (no 64-bit address per tensor and row, no vectors for an absent residual gradient).
+template <int NV, bool DROPPED, bool CS, bool ADD>
+__global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(int64_t rows, const bf16_t* __restrict__ dy, int64_t lddy,
+                                                                const bf16_t* __restrict__ x, int64_t ldx,
+                                                                const bf16_t* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const bf16_t* __restrict__ add,
+                                                                int64_t ldadd, bf16_t* __restrict__ dx, int64_t lddx,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                int rows_per_wave, bf16_t* __restrict__ dxd, int64_t lddxd,
+                                                                DropCfg drop, float* __restrict__ colsum) {
+  constexpr int D = 256 * NV, VN = 4;
+  typedef VecH<bf16_t> V;
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = (float*)smem_raw;  // [4 waves][D]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
+  const int64_t r1 = (r0 + rows_per_wave < rows) ? r0 + rows_per_wave : rows;
+  const int nrow = r0 < r1 ? (int)(r1 - r0) : 0;
+  auto desc = [&](const void* p, int64_t ld) {
+    const int64_t bytes = (int64_t)nrow * ld * 2;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p + (nrow ? r0 * ld * 2 : 0)), 0,
+                                             (unsigned)(p == nullptr ? 0 : bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : bytes), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rs_dy = desc(dy, lddy), rs_x = desc(x, ldx), rs_add = desc(ADD ? add : nullptr, ldadd),
+                               rs_dx = desc(dx, lddx), rs_dxd = desc(DROPPED ? dxd : nullptr, lddxd);
+  const int s_dy = (int)(lddy * 2), s_x = (int)(ldx * 2), s_add = (int)(ldadd * 2), s_dx = (int)(lddx * 2), s_dxd = (int)(lddxd * 2);
+  const int voff = lane * 8;
+  auto ld8 = [&](__amdgpu_buffer_rsrc_t rs, int i, int soff) {
+    V v;
+    v.v = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, voff + i * 512, soff, 0));
+    return v;
+  };
+  auto st8 = [&](__amdgpu_buffer_rsrc_t rs, int i, int soff, const V& v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v.v), rs, voff + i * 512, soff, 0);
+  };
+  float pg[NV][VN], pb[NV][VN], pc[CS ? NV : 1][CS ? VN : 1];
+  V gv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    gv[i] = *(const V*)(gamma + (i * 64 + lane) * VN);
+#pragma unroll
+    for (int j = 0; j < VN; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; if constexpr (CS) pc[i][j] = 0.f; }
+  }
+  V xv[NV], gy[NV], av[ADD ? NV : 1], xn[NV], gn[NV], an[ADD ? NV : 1];
+  float mu = 0.f, rs = 0.f, mu_n = 0.f, rs_n = 0.f;
+  if (nrow) {
+    mu = mean[r0]; rs = rstd[r0];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      xv[i] = ld8(rs_x, i, 0);
+      gy[i] = ld8(rs_dy, i, 0);
+      if constexpr (ADD) av[i] = ld8(rs_add, i, 0);
+    }
+  }
+  for (int k = 0; k < nrow; ++k) {
+    const int64_t row = r0 + k;
+    if (k + 1 < nrow) {
+      mu_n = mean[row + 1]; rs_n = rstd[row + 1];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        xn[i] = ld8(rs_x, i, (k + 1) * s_x);
+        gn[i] = ld8(rs_dy, i, (k + 1) * s_dy);
+        if constexpr (ADD) an[i] = ld8(rs_add, i, (k + 1) * s_add);
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+#pragma unroll
+      for (int j = 0; j < VN; ++j) {
+        const float xh = (xv[i].get(j) - mu) * rs;
+        const float g = gy[i].get(j);
+        const float gg = g * gv[i].get(j);
+        s1 += gg;
+        s2 += gg * xh;
+        pg[i][j] += g * xh;
+        pb[i][j] += g;
+      }
+    }
+    const float m1 = wave_sum_dpp(s1) / (float)D, m2 = wave_sum_dpp(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * VN;
+      V o, od;
+      float ds0 = 0.f, ds1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < VN; ++j) {
+        const float xh = (xv[i].get(j) - mu) * rs;
+        float v = rs * (gy[i].get(j) * gv[i].get(j) - m1 - xh * m2);
+        if constexpr (ADD) v += av[i].get(j);
+        o.set(j, v);
+        if constexpr (DROPPED) {
+          if ((j & 1) == 0) drop_scale2(drop, (uint64_t)row * D + c + j, ds0, ds1);
+          v = o.get(j) * ((j & 1) ? ds1 : ds0);
+          od.set(j, v);
+          v = od.get(j);
+        } else {
+          v = o.get(j);
+        }
+        if constexpr (CS) pc[i][j] += v;
+      }
+      st8(rs_dx, i, k * s_dx, o);
+      if constexpr (DROPPED) st8(rs_dxd, i, k * s_dxd, od);
+    }
+    mu = mu_n; rs = rs_n;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { xv[i] = xn[i]; gy[i] = gn[i]; if constexpr (ADD) av[i] = an[i]; }
+  }
+  if (!dgamma && !dbeta && !colsum) return;
+  constexpr int W = D;
+#pragma unroll
+  for (int round = 0; round < (CS ? 3 : 2); ++round) {
+    float* dst = round == 0 ? dgamma : round == 1 ? dbeta : colsum;
+    if (round) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = 0; j < VN; ++j)
+        red[wave * W + (i * 64 + lane) * VN + j] = round == 0 ? pg[i][j] : round == 1 ? pb[i][j] : pc[CS ? i : 0][CS ? j : 0];
+    __syncthreads();
+    if (dst)
+      for (int c = threadIdx.x; c < D; c += 256) atomicAdd(dst + c, red[c] + red[W + c] + red[2 * W + c] + red[3 * W + c]);
+  }
+}
+
 template <typename T>
 static int ln_fwd_dispatch(hipStream_t st, int64_t rows, int D, const void* x, int64_t ldx, const void* gamma,
                            const void* beta, float eps, void* y, int64_t ldy, float* mean, float* rstd, void* q8 = nullptr,
@@ -413,11 +545,35 @@ static int ln_bwd_dispatch(hipStream_t st, int64_t rows, int D, const void* dy, 
   constexpr int VN = Vec<T>::N;
   const int nv = (D + 64 * VN - 1) / (64 * VN);
   // ~2048 workgroups x 4 waves, at least 4 rows per wave so the column atomics stay few
-  int rpw = (int)((rows + 2048 * 4 - 1) / (2048 * 4));
+  const int64_t want = switches().ln_bwd_wgs > 0 ? switches().ln_bwd_wgs : 2048;
+  int rpw = (int)((rows + want * 4 - 1) / (want * 4));
   if (rpw < 4) rpw = 4;
   const unsigned grid = (unsigned)((rows + 4 * rpw - 1) / (4 * rpw));
   const bool tail = dxd != nullptr || colsum != nullptr;
   if constexpr (std::is_same<T, bf16_t>::value) {
+    // row offsets inside a wave's block of rows are 32-bit scalars: rows_per_wave * row stride stays far below 2^31
+    const int64_t ldmax = std::max(std::max(lddy, ldx), std::max(std::max(ldadd, lddx), lddxd));
+    if ((D == 768 || D == 1024 || D == 512 || D == 256) && !switches().ln_generic && (int64_t)rpw * ldmax * 2 < (1ll << 31)) {
+#define LN_BWD_S(NV_, DR_, CS_, ADD_) hipLaunchKernelGGL((layernorm_bwd_rows_kernel<NV_, DR_, CS_, ADD_>), grid, 256, (size_t)(4 * 256 * NV_ * 4), st, rows, \
+                       (const T*)dy, lddy, (const T*)x, ldx, (const T*)gamma, mean, rstd, (const T*)add, ldadd,  \
+                       (T*)dx, lddx, dgamma, dbeta, rpw, (T*)dxd, lddxd, drop, colsum)
+#define LN_BWD_F(NV_)                                          \
+      switch (form) {                                          \
+        case 0: LN_BWD_S(NV_, false, false, false); break;     \
+        case 1: LN_BWD_S(NV_, false, false, true); break;      \
+        case 2: LN_BWD_S(NV_, false, true, false); break;      \
+        case 3: LN_BWD_S(NV_, false, true, true); break;       \
+        case 4: LN_BWD_S(NV_, true, false, false); break;      \
+        case 5: LN_BWD_S(NV_, true, false, true); break;       \
+        case 6: LN_BWD_S(NV_, true, true, false); break;       \
+        default: LN_BWD_S(NV_, true, true, true); break;       \
+      }
+      const int form = (dxd ? 4 : 0) | (colsum ? 2 : 0) | (add ? 1 : 0);
+      if (D == 768) { LN_BWD_F(3) } else if (D == 1024) { LN_BWD_F(4) } else if (D == 512) { LN_BWD_F(2) } else { LN_BWD_F(1) }
+#undef LN_BWD_F
+#undef LN_BWD_S
+      return check_launch("layernorm_bwd");
+    }
     if (D == 768) {
 #define LN_BWD_H(TAIL_, CS_) hipLaunchKernelGGL((layernorm_bwd_kernel<T, 3, TAIL_, CS_, VecH<T>>), grid, 256, (size_t)(4 * 768 * 4), st, rows, D, \
                        (const T*)dy, lddy, (const T*)x, ldx, (const T*)gamma, mean, rstd, (const T*)add, ldadd,  \

@@ -372,6 +372,57 @@ def test_layernorm(ops, dtype, D):
     torch.testing.assert_close(db.cpu(), br.grad, atol=5e-3 if dtype == torch.bfloat16 else 2e-4, rtol=1e-3)
 
 
+@pytest.mark.parametrize("D", [256, 512, 768, 1024])
+@pytest.mark.parametrize("form", range(8))
+def test_layernorm_backward_with_scalar_row_addresses_changes_no_bit(ops, D, form):
+    """bf16 rows of 256 * NV elements take layernorm_bwd_rows_kernel (row offsets in SGPRs through buffer descriptors: 88-114
+    VGPRs against 134-202, csrc/layernorm.hip); MDT_LN_GENERIC=1 sends the same call to the generic kernel.  Same arithmetic, and for
+    768 columns in the same order: dx and the dropped copy are bit-identical there (within a bf16 ulp for the other widths) in all eight forms (residual gradient / dropped copy / column sums
+    present or not), strided rows included; the three column sums are fp32 atomics across workgroups — equal up to their order.
+    1031 rows: the last wave's block is short, some waves of the last workgroup have no row at all."""
+    import os
+    bf = torch.bfloat16
+    rows, ld = 1031, D + 64
+    has_add, has_cs, has_drop = bool(form & 1), bool(form & 2), bool(form & 4)
+    x = dev(rnd(rows, ld, seed=1, scale=2.0).to(bf))[:, :D]
+    dy = dev(rnd(rows, ld, seed=2).to(bf))[:, :D]
+    add = dev(rnd(rows, ld, seed=3).to(bf))[:, :D] if has_add else None
+    g = dev((1 + 0.1 * rnd(D, seed=4)).to(bf))
+    b = dev((0.1 * rnd(D, seed=5)).to(bf))
+    _, mean, rstd = ops.layernorm_fwd(x.contiguous(), g, b, 1e-12)
+
+    def run():
+        dg, db = torch.zeros(D, dtype=torch.float32).cuda(), torch.zeros(D, dtype=torch.float32).cuda()
+        cs = torch.zeros(D, dtype=torch.float32).cuda() if has_cs else None
+        dx = torch.full((rows, ld), 3.0, dtype=bf).cuda()[:, :D]
+        out = ops.layernorm_bwd(dy, x, g, mean, rstd, add=add, dgamma=dg, dbeta=db, dx=dx, drop_p=0.4 if has_drop else 0.0, drop_seed=77,
+                                colsum=cs, want_dropped=has_drop)
+        dxd = out[1] if has_drop else None
+        torch.cuda.synchronize()
+        return dx.clone(), None if dxd is None else dxd.clone(), dg, db, cs
+
+    try:
+        os.environ["MDT_LN_GENERIC"] = "1"
+        L.reload_env()
+        ref = run()
+    finally:
+        os.environ.pop("MDT_LN_GENERIC", None)
+        L.reload_env()
+    got = run()
+    def same(a, r):
+        if D == 768:                    # the generic kernel on the same 8-byte vectors: the same sums in the same order
+            assert torch.equal(a, r)
+        else:                           # the generic kernel sums a row over 16-byte vectors on fewer lanes: another order, <= 1 bf16 ulp
+            torch.testing.assert_close(a.float(), r.float(), atol=2e-3, rtol=2.0 ** -7)
+    same(got[0], ref[0])
+    if has_drop:
+        same(got[1], ref[1])
+        assert not torch.equal(got[1], got[0])
+    for a, r in zip(got[2:], ref[2:]):
+        if r is not None:
+            torch.testing.assert_close(a, r, atol=2e-4 * max(1.0, float(r.abs().max())), rtol=1e-5)
+
+
 # ----------------------------------------------------------------------------- attention
 def ref_attention(qkv, nseq, S, H, scale, bias):
     """qkv [nseq,S,3D] fp32 (requires_grad), bias [nseq,H,S,S] additive (may hold -inf)."""

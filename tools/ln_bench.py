@@ -45,6 +45,13 @@ def main():
         flip[0] ^= 1
         return (x, dy, add) if flip[0] else (x2, dy2, add2)
 
+    # yardsticks: what the part gives the simplest streaming kernels at the same size (the vendor's copy and a three-stream add)
+    t = timeit(lambda: y.copy_(pick()[0]))
+    print(f"yardstick: torch copy_               rows {rows} D {D}: {t * 1e6:7.1f} us  {2 * el / t / 1e12:5.2f} TB/s = {2 * el / t / 8e12:4.2f} of HBM peak (1 read, 1 write)")
+    t = timeit(lambda: torch.add(pick()[0], pick()[1], out=y))
+    print(f"yardstick: torch add(out=)           rows {rows} D {D}: {t * 1e6:7.1f} us  {3 * el / t / 1e12:5.2f} TB/s = {3 * el / t / 8e12:4.2f} of HBM peak (2 reads, 1 write)")
+    t = timeit(lambda: pick()[0].float().sum() if False else torch.sum(pick()[0], dtype=torch.float32))
+    print(f"yardstick: torch sum (read only)     rows {rows} D {D}: {t * 1e6:7.1f} us  {el / t / 1e12:5.2f} TB/s = {el / t / 8e12:4.2f} of HBM peak (1 read)")
     t = timeit(lambda: ops.layernorm_fwd(pick()[0], gamma, beta, 1e-12, out=y))
     print(f"forward                              rows {rows} D {D}: {t * 1e6:7.1f} us  {2 * el / t / 1e12:5.2f} TB/s = {2 * el / t / 8e12:4.2f} of HBM peak (x read, y written)")
     dx = torch.empty_like(x)

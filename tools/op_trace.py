@@ -1,0 +1,150 @@
+"""Which launch is the first to differ?  Training step 0 of the fp8 model (or the bf16 one with --bf16) from identical weights, batch
+and seeds, `reps` times in one process; every call into `ops` (the C-ABI wrappers) is traced: clones of all its tensor arguments
+before and after the call in repetition 0, compared on the fly in the later repetitions.  Prints the first call whose result differs
+by more than what fp32 atomics explain, whether its inputs still agreed, and where in the tensor the difference sits.
+GPU box only:  python tools/op_trace.py [reps] [--bf16] [--alone] [--one-stream]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multimodaldiscussiontransformer_amd import fp8, ops  # noqa: E402
+from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy  # noqa: E402
+from multimodaldiscussiontransformer_amd.data.packer import pack_batch  # noqa: E402
+from multimodaldiscussiontransformer_amd.models import GraphormerModel  # noqa: E402
+from tests.test_oracle_golden import full_case  # noqa: E402
+from tests.util_model import fill_hash_weights, model_args  # noqa: E402
+
+TOL = 1e-5          # relative to the tensor's max |value|: fp32 atomics in another order stay far below
+
+
+class Tracer:
+    def __init__(self):
+        self.ref = None          # repetition 0: list of (name, before clones, after clones)
+        self.cur = []
+        self.idx = 0
+        self.first = None
+        self.recording = False
+
+    def tensors(self, args, kwargs):
+        out = []
+        for k, v in list(enumerate(args)) + sorted(kwargs.items(), key=lambda kv: str(kv[0])):
+            if isinstance(v, torch.Tensor) and v.is_cuda:
+                out.append((str(k), v))
+            elif isinstance(v, (tuple, list)):
+                for j, w in enumerate(v):
+                    if isinstance(w, torch.Tensor) and w.is_cuda:
+                        out.append((f"{k}[{j}]", w))
+        return out
+
+    def wrap(self, name, fn):
+        def inner(*args, **kwargs):
+            if not self.recording:
+                return fn(*args, **kwargs)
+            ts = self.tensors(args, kwargs)
+            before = [(k, t.detach().clone()) for k, t in ts]
+            res = fn(*args, **kwargs)
+            rts = self.tensors((res,) if not isinstance(res, tuple) else res, {})
+            after = [(k, t.detach().clone()) for k, t in ts] + [("ret" + k, t.detach().clone()) for k, t in rts]
+            if self.ref is None:
+                self.cur.append((name, before, after))
+            elif self.first is None:
+                self.compare(name, before, after)
+            self.idx += 1
+            return res
+        return inner
+
+    @staticmethod
+    def diff(a, b):
+        if a.shape != b.shape or a.dtype != b.dtype:
+            return float("inf"), "shape/dtype"
+        if a.numel() == 0:
+            return 0.0, ""
+        af, bf_ = a.float(), b.float()
+        bad_a, bad_b = ~torch.isfinite(af), ~torch.isfinite(bf_)
+        if bool((bad_a != bad_b).any()):
+            return float("inf"), f"non-finite pattern differs ({int(bad_a.sum())} vs {int(bad_b.sum())})"
+        af, bf_ = torch.where(bad_a, torch.zeros_like(af), af), torch.where(bad_b, torch.zeros_like(bf_), bf_)
+        d = (af - bf_).abs()
+        m = float(d.max())
+        scale = max(float(bf_.abs().max()), 1e-30)
+        where = ""
+        if m / scale > TOL:
+            flat = d.reshape(-1)
+            nbad = int((flat > TOL * scale).sum())
+            i = int(flat.argmax())
+            where = f"{nbad} of {flat.numel()} elements beyond tolerance, worst at flat index {i} (shape {tuple(a.shape)}): {float(af.reshape(-1)[i]):.6g} vs {float(bf_.reshape(-1)[i]):.6g}"
+            if a.dim() == 2:
+                rows = (d > TOL * scale).any(1).nonzero().flatten()
+                cols = (d > TOL * scale).any(0).nonzero().flatten()
+                where += f"; rows {rows[:6].tolist()}..{rows[-3:].tolist()} ({rows.numel()}), cols {cols[:6].tolist()}..{cols[-3:].tolist()} ({cols.numel()})"
+        return m / scale, where
+
+    def compare(self, name, before, after):
+        if self.idx >= len(self.ref) or self.ref[self.idx][0] != name:
+            self.first = f"call {self.idx}: the sequence itself differs ({name} vs {self.ref[self.idx][0] if self.idx < len(self.ref) else 'end'})"
+            return
+        _, rb, ra = self.ref[self.idx]
+        for (k, t), (k2, r) in zip(after, ra):
+            d, where = self.diff(t, r)
+            if d > TOL:
+                ins = []
+                for (kb, tb), (_, rbb) in zip(before, rb):
+                    db, _ = self.diff(tb, rbb)
+                    ins.append(f"{kb}: {'same' if db == 0 else f'{db:.1e}'}")
+                self.first = (f"call {self.idx} {name}: argument {k} differs after the call by {d:.3e} of its max — {where}\n"
+                              f"      arguments BEFORE the call vs repetition 0: {', '.join(ins)}")
+                return
+
+
+def run(tr, bf16, fused, one_stream, trace):
+    fname, hp, trees, over = full_case("C2")
+    fp8.FUSED_Q = fused
+    torch.manual_seed(11)
+    model = GraphormerModel.build_model(model_args(hp), task=None)
+    fill_hash_weights(model, overrides=over)
+    model = model.cuda().bfloat16().train()
+    model.prepare_main_grads()
+    if one_stream:
+        model.encoder.graph_encoder.two_streams = False
+    st = None if bf16 else model.enable_fp8()
+    try:
+        pb = pack_batch(trees, 5)
+        crit = GraphPredictionNodeCrossEntropy(None, positive_weight=hp.pos_weight, negative_weight=hp.neg_weight)
+        torch.manual_seed(100)
+        model.zero_main_grads()
+        torch.cuda.synchronize()
+        tr.recording, tr.idx = trace, 0
+        loss, n, log = crit(model, {"nsamples": len(trees), "net_input": {"batched_data": pb.batched_data}})
+        loss.backward()
+        torch.cuda.synchronize()
+        tr.recording = False
+        return float(loss), model.main_grad_flat.clone(), (st.scale[:len(st.sites)].clone() if st is not None else None)
+    finally:
+        fp8.ACTIVE = None
+
+
+def main():
+    argv = sys.argv[1:]
+    reps = int(argv[0]) if argv and argv[0].isdigit() else 5
+    bf16, alone, one_stream = "--bf16" in argv, "--alone" in argv, "--one-stream" in argv
+    tr = Tracer()
+    for name in ops.__all__:
+        fn = getattr(ops, name, None)
+        if callable(fn) and not isinstance(fn, type):
+            setattr(ops, name, tr.wrap(name, fn))
+    loss0, g0, s0 = run(tr, bf16, not alone, one_stream, True)
+    tr.ref, tr.cur = tr.cur, []
+    print(f"repetition 0: {len(tr.ref)} traced calls, loss {loss0:.8f}, |g| {float(g0.norm()):.6f}", flush=True)
+    for rep in range(1, reps):
+        tr.first = None
+        loss, g, s = run(tr, bf16, not alone, one_stream, True)
+        gd = float((g - g0).norm() / g0.norm())
+        sd = int((s != s0).sum()) if s is not None else 0
+        print(f"repetition {rep}: loss d {loss - loss0:+.2e}, gradient rel-L2 {gd:.2e}, first scales differing {sd}; "
+              + (f"FIRST DIFFERENCE: {tr.first}" if tr.first else "no traced call differs"), flush=True)
+
+
+if __name__ == "__main__":
+    main()
