@@ -615,9 +615,10 @@ static int dispatch(hipStream_t st, const AttnParams& p) {
       // (plain rows of up to 80 tokens take the one-pass kernel since round 4 — 3 x faster, 749 -> 225 us on 2048 ragged sequences
       // of 10-64 tokens — now that its short-row form sums delta = sum P o dP itself, in fp32, like the scratch kernel does
       // (attn_bwd_v4x); graphs with a structural bias stay here)
-      const bool v1 = force ? !strcmp(force, "v1") : (a.S <= 80 && (st_bias || !switches().attn_exact_delta));
-      // the whole-row v2 backward knows nothing of q_limit (rows the forward skipped have no lse): those launches take v3 / v4
-      const bool v2 = (force ? !strcmp(force, "v2") : (!drop && a.q_limit == 0)) && a.S <= 112;
+      // neither the scratch kernel nor the whole-row v2 backward knows of q_limit (they would read the out / lse rows the v2 FORWARD
+      // skipped — unwritten memory): such launches take v3 / v4 whatever MDT_ATTN_BWD says (tests: ..._never_reads_what_forward_did_not_write)
+      const bool v1 = force ? (!strcmp(force, "v1") && a.q_limit == 0) : (a.S <= 80 && a.q_limit == 0 && (st_bias || !switches().attn_exact_delta));
+      const bool v2 = (force ? !strcmp(force, "v2") : !drop) && a.q_limit == 0 && a.S <= 112;
       if (!v1) return v2 ? attention_v2_dispatch(st, p, true) : attention_v3_bwd_dispatch(st, p);
     }
     if (a.hd == 64) return st_bias ? dispatch_nt<bf16_t, 64, true, BWD>(st, p) : dispatch_nt<bf16_t, 64, false, BWD>(st, p);

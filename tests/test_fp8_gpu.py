@@ -328,7 +328,16 @@ def test_fp8_producer_quantised_operands_equal_stand_alone_passes(monkeypatch):
     assert fused_n > 0 and fused_0 == 0 and gemms_f == gemms_s, (fused_n, fused_0, gemms_f, gemms_s)
     print(f"[fp8 fused vs stand-alone] logits sums {float(lg_f.double().sum()):.10f} / {float(lg_s.double().sum()):.10f}, max |diff| {float((lg_f - lg_s).abs().max()):.3e}, "
           f"first rows {lg_f[0].tolist()} / {lg_s[0].tolist()}")
-    assert torch.equal(lg_f, lg_s)
+    if not torch.equal(lg_f, lg_s):
+        # seen on SOME devices of the pool only: say which launch of a training step does not repeat itself there
+        import os
+        import subprocess
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        tr = subprocess.run([sys.executable, os.path.join(root, "tools", "op_trace.py"), "4"], capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in tr.stdout.splitlines() if ln.startswith("repetition") or "SUSPICIOUS" in ln]
+        pytest.fail("fused and stand-alone routes differ (max |diff| %.3e); tools/op_trace.py on this device:\n%s" %
+                    (float((lg_f - lg_s).abs().max()), "\n".join(lines)[:4000]))
     # gradients: the split-K weight gradients add their slabs with fp32 atomics in whatever order they finish — equal up to that
     assert float((g_f.double() - g_s.double()).norm() / g_s.double().norm()) < 1e-5
 

@@ -801,6 +801,52 @@ def test_attention_ragged_sequences_equal_masked_padding(ops, dtype, bwd, Smax, 
         torch.testing.assert_close(lse_r[s_, :, :n].cpu(), lse_p[s_, :, :n].cpu(), atol=1e-4, rtol=1e-5)
 
 
+@pytest.mark.parametrize("route", [None, "v1", "v2", "v3"])
+@pytest.mark.parametrize("Smax,qlim", [(40, 0), (104, 0), (201, 0), (88, 0), (104, 9), (201, 33)])
+def test_attention_backward_never_reads_what_forward_did_not_write(ops, route, Smax, qlim, monkeypatch):
+    """Forward leaves the log-sum-exp of positions past a sequence's length (ragged batches: [nseq, H, Smax] is a dense buffer) and
+    of query rows past q_limit (rounded up to its 16-row tile) unwritten, and with q_limit the output rows past that too: stale bytes of whatever the allocator handed
+    out.  Backward must not let them reach a result — not even multiplied by a zero dO (inf * 0).  The same backward call with
+    those positions set to NaN, to +inf, to -1e30 and to 0: bit-identical, finite gradients, on every kernel family (tools/op_trace.py
+    found the unwritten positions differing between repetitions of one training step)."""
+    bf = torch.bfloat16
+    if route == "v2" and Smax > 112:
+        pytest.skip("whole-row backward covers S <= 112")
+    if route:
+        monkeypatch.setenv("MDT_ATTN_BWD", route)
+        L.reload_env()
+    H, hd, p, seed = 3, 64, 0.2, 5
+    D = H * hd
+    lens = [Smax, 1, 17, Smax - 3, 5, min(33, Smax - 1), Smax - 16, 16]
+    nseq = len(lens)
+    off = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    rows = int(off[-1])
+    qkv = dev(rnd(rows, 3 * D, seed=3).to(bf))
+    dout = rnd(rows, D, seed=4).to(bf)
+    valid_q = torch.zeros(nseq, Smax, dtype=torch.bool)
+    row_live = torch.ones(rows, dtype=torch.bool)
+    for s_, n in enumerate(lens):
+        nq = min(n, qlim) if qlim else n
+        nw = min(n, (qlim + 15) & ~15) if qlim else n      # forward computes (and writes) whole 16-row query tiles
+        valid_q[s_, :nw] = True
+        row_live[int(off[s_]) + nw:int(off[s_]) + n] = False
+        dout[int(off[s_]) + nq:int(off[s_]) + n] = 0       # what the engine hands over for rows nobody asked for
+    dout = dev(dout)
+    kw = dict(drop_p=p, drop_seed=seed, seq_offsets=dev(off), q_limit=qlim)
+    out, lse = ops.attention_fwd(qkv, nseq, Smax, H, **kw)
+    vq = dev(valid_q)[:, None, :].expand(nseq, H, Smax)
+    live = dev(row_live)[:, None]
+    res = []
+    for poison in (float("nan"), float("inf"), -1e30, 0.0):
+        lse_p = torch.where(vq, lse, torch.full_like(lse, poison))
+        out_p = torch.where(live, out, torch.full_like(out, poison))
+        dq, _ = ops.attention_bwd(dout, qkv, out_p, lse_p, nseq, Smax, H, **kw)
+        assert bool(torch.isfinite(dq.float()).all()), poison
+        res.append(dq)
+    for r in res[1:]:
+        assert torch.equal(r, res[0])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("S,H,qlim", [(104, 3, 5), (201, 2, 1), (40, 2, 17)])
 def test_attention_query_limit(ops, dtype, S, H, qlim):
