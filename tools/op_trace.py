@@ -3,7 +3,9 @@ and seeds, `reps` times in one process; every call into `ops` (the C-ABI wrapper
 before and after the call in repetition 0, compared on the fly in the later repetitions.  Prints the calls whose results differ
 by more than what fp32 atomics explain, whether their inputs still agreed (suspicious) or an output buffer already differed before
 the call (unwritten rows a later call fills), and where in the tensor the difference sits.
-GPU box only:  python tools/op_trace.py [reps] [--bf16] [--alone] [--one-stream]"""
+--poison: fresh allocations are filled with 0 in repetition 0 and with NaN / 1e30 / -1e30 / 65504 in the later ones — a launch that reads a
+buffer nobody wrote differs on EVERY device then.
+GPU box only:  python tools/op_trace.py [reps] [--bf16] [--alone] [--one-stream] [--poison]"""
 import os
 import sys
 
@@ -137,6 +139,31 @@ def run(tr, bf16, fused, one_stream, trace):
         fp8.ACTIVE = None
 
 
+_REAL = {}
+
+
+def poison_allocations(value):
+    """Every torch.empty / empty_like / new_empty returns memory filled with `value` (None: leave them alone): what a kernel reads
+    from a buffer nobody wrote is then the same on every device — 0 in repetition 0, NaN / 1e30 afterwards — and a launch that lets
+    it reach a result shows up as SUSPICIOUS in the trace.  uint8 buffers (fp8 operands) get 0x00 / 0x7f (e4m3 NaN)."""
+    if not _REAL:
+        _REAL.update(empty=torch.empty, empty_like=torch.empty_like, new_empty=torch.Tensor.new_empty)
+    if value is None:
+        torch.empty, torch.empty_like, torch.Tensor.new_empty = _REAL["empty"], _REAL["empty_like"], _REAL["new_empty"]
+        return
+
+    def fill(t):
+        if t.is_cuda and t.numel():
+            if t.dtype == torch.uint8:
+                t.fill_(0 if value == 0 else 0x7F)
+            elif t.is_floating_point():
+                t.fill_(value)
+        return t
+    torch.empty = lambda *a, **k: fill(_REAL["empty"](*a, **k))
+    torch.empty_like = lambda *a, **k: fill(_REAL["empty_like"](*a, **k))
+    torch.Tensor.new_empty = lambda self, *a, **k: fill(_REAL["new_empty"](self, *a, **k))
+
+
 def main():
     argv = sys.argv[1:]
     reps = int(argv[0]) if argv and argv[0].isdigit() else 5
@@ -146,11 +173,18 @@ def main():
         fn = getattr(ops, name, None)
         if callable(fn) and not isinstance(fn, type):
             setattr(ops, name, tr.wrap(name, fn))
+    poison = "--poison" in argv
+    fills = [0.0, float("nan"), 1e30, -1e30, 65504.0]
+    if poison:
+        poison_allocations(fills[0])
     loss0, g0, s0 = run(tr, bf16, not alone, one_stream, True)
     tr.ref, tr.cur = tr.cur, []
     print(f"repetition 0: {len(tr.ref)} traced calls, loss {loss0:.8f}, |g| {float(g0.norm()):.6f}", flush=True)
     for rep in range(1, reps):
         tr.found = []
+        if poison:
+            poison_allocations(fills[rep % len(fills)])
+            print(f"   (fresh allocations filled with {fills[rep % len(fills)]})", flush=True)
         loss, g, s = run(tr, bf16, not alone, one_stream, True)
         gd = float((g - g0).norm() / g0.norm())
         sd = int((s != s0).sum()) if s is not None else 0
