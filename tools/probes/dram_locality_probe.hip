@@ -53,6 +53,34 @@ __global__ __launch_bounds__(256) void stream(const char* __restrict__ A, long M
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// The output side: a 256 x 256 bf16 tile leaves as 16-row x 64-byte store instructions (the register epilogue's pattern: a lane
+// holds 8 consecutive columns of one row) into a row-major [M, N] matrix (rows 2 N bytes apart) — or, blocked, into one contiguous
+// 128 KiB per tile.  MODE 2: strided, 3: blocked.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+template <int MODE>
+__global__ __launch_bounds__(256) void store_tiles(char* __restrict__ C, long M, long N, int tiles_m, int tiles_n) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int c_lane = lane & 15, g_lane = lane >> 4;
+  const long ld_b = N * 2;
+  const i32x4 v = i32x4{lane, wave, 3, 4};
+  for (int t = blockIdx.x; t < tiles_m * tiles_n; t += gridDim.x) {
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    char* base = MODE == 2 ? C + (long)tm * 256 * ld_b + (long)tn * 512 : C + (long)t * 131072;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xFFFFFFF0u, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned voff;
+        if (MODE == 2) voff = (unsigned)((wr * 128 + i * 16 + c_lane) * ld_b + (wc * 128 + j * 32 + 16 * (g_lane & 1) + 8 * (g_lane >> 1)) * 2);
+        else voff = (unsigned)(((wave * 8 + i) * 4 + j) * 1024 + lane * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, 0, 0);
+      }
+  }
+}
+
 int main(int argc, char** argv) {
   const long M = argc > 1 ? atol(argv[1]) : 100864, K = argc > 2 ? atol(argv[2]) : 3072;
   const long Mp = (M + 255) / 256 * 256;
@@ -85,6 +113,20 @@ int main(int argc, char** argv) {
   RUN(0, 2, 1); RUN(1, 2, 1);
   RUN(0, 2, 2); RUN(1, 2, 2);
   RUN(0, 1, 4); RUN(1, 1, 4);
+#define RUNS(MODE)                                                                                              \
+  {                                                                                                             \
+    float best = 1e9f;                                                                                          \
+    for (int it = 0; it < 6; ++it) {                                                                            \
+      char* dst = (it & 1) ? A : B;                                                                             \
+      hipEventRecord(e0);                                                                                       \
+      hipLaunchKernelGGL((store_tiles<MODE>), dim3(cus), dim3(256), 0, 0, dst, Mp, K, tiles, (int)(K / 256));   \
+      hipEventRecord(e1); hipEventSynchronize(e1);                                                              \
+      float ms; hipEventElapsedTime(&ms, e0, e1);                                                               \
+      if (it >= 2 && ms < best) best = ms;                                                                      \
+    }                                                                                                           \
+    printf("stores %-8s (256 x 256 tiles of a %ld-column matrix): %7.1f us  %5.2f TB/s\n", MODE == 2 ? "strided" : "blocked", K, best * 1e3, bytes / (best * 1e-3) / 1e12); \
+  }
+  RUNS(2); RUNS(3);
   hipError_t e = hipDeviceSynchronize();
   printf("%s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
   return e == hipSuccess ? 0 : 1;
