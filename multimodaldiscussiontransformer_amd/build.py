@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmdt_hip.so")
-SOURCES = ["gemm.hip", "gemm_wgrad.hip", "gemm_solo.hip", "gemm_f8.hip", "layernorm.hip", "attention.hip", "attention_v2.hip", "attention_long.hip", "rowops.hip", "patch_embed.hip", "contrastive.hip", "fp8.hip", "optim.hip", "image.hip", "host.cpp"]
+SOURCES = ["gemm.hip", "gemm_wgrad.hip", "gemm_f8.hip", "layernorm.hip", "attention.hip", "attention_v2.hip", "attention_long.hip", "rowops.hip", "patch_embed.hip", "contrastive.hip", "fp8.hip", "optim.hip", "image.hip", "host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-ffp-contract=off"]
 # attention: keep MFMA results in VGPRs — the softmax works on the accumulators in place, and with the default
 # AGPR form the compiler spends 10-15 % of the VALU stream on v_accvgpr_read/write copies (gfx950's file is unified)

@@ -50,8 +50,6 @@ struct Switches {
   bool gemm_no_pp;           // MDT_GEMM_NO_PP
   int gemm_f8w;              // MDT_GEMM_F8W       (default 1: 8-bit GEMMs on the 16x16x128 block-MFMA kernel where it has an instantiation; 0: the 8-wave kernel)
   int gemm_w4;               // MDT_GEMM_W4        (default 2: the 4-wave persistent kernel where it is measured faster; 0: never; 1: every persistent launch)
-  int gemm_solo;             // MDT_GEMM_SOLO      (4-wave 128 x 256 kernel at two workgroups per CU: 0 never; 1 the GELU launches; 2 also bias / bias + dropout + residual)
-  int gemm_solo_skew;        // MDT_GEMM_SOLO_SKEW (-1: half a tile; n: 64-cycle sleeps the second workgroup of a CU starts late)
   bool attn_v1;              // MDT_ATTN_V1
   char attn_bwd[8];          // MDT_ATTN_BWD       ("" unset)
   bool attn_no_occ4;         // MDT_ATTN_NO_OCC4

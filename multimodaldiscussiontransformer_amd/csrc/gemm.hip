@@ -1242,14 +1242,6 @@ static int launch_pp256(hipStream_t st, const GemmParams& p_in, int ta, int tb) 
   const bool persist = sw.gemm_persist != 0 && sizeof(TOut) == 2 && p.split_k == 1 && nhs_total >= min_steps && (int)grid.x > num_cus();
   if (persist) grid.x = (unsigned)num_cus();
   p.tile_queue = nullptr;
-  if (persist && sw.gemm_solo > 0 && !sw.gemm_no_spec && !sw.gemm_stamp && !(p.epilogue & (0x7f << 20))) {
-    // MDT_GEMM_SOLO: 1 = the GELU launches (fc1 forward), 2 = also the bias and bias + dropout + residual launches
-    const int e_ = p.epilogue & ((1 << 22) - 1);
-    if (sw.gemm_solo >= 2 || e_ == (MDT_EPI_BIAS | MDT_EPI_GELU | MDT_EPI_AUX_GRAD)) {
-      const int r = launch_solo(st, p, ta, tb, num_cus());
-      if (r != -1) return r;
-    }
-  }
   if (persist && nhs_total >= W4_NEXPL + 2) {
     // MDT_GEMM_W4: 0 off; 1 every persistent launch; 2 the launches it is measured faster on (k-contiguous operands, light
     // epilogues: plain, bias, residual, bias + dropout + residual, saved derivative + column sums — not the GELU form, not k-major operands)

@@ -27,7 +27,6 @@ struct GemmParams {
   // 8-bit kernel only (gemm_f8.hip): the output ALSO leaves as fp8 for the next 8-bit GEMM — q8_out u8[M, N] = saturate(fmt,
   // bf16(out) * *q8_scale), *q8_amax = max(*q8_amax, max |bf16(out)|): exactly what mdt_fp8_quantize would make of the bf16 output
   void* q8_out = nullptr; int64_t ld_q8 = 0; const float* q8_scale = nullptr; float* q8_amax = nullptr; int q8_fmt = 0;
-  int solo_skew = 0;            // gemm_bf16_solo: the second workgroup of a CU starts this many 64-cycle sleeps late (its epilogues then fall into the first one's K loops)
 };
 
 template <typename TIn, typename TOut>
@@ -353,8 +352,6 @@ __device__ __forceinline__ void w4_dma(__amdgpu_buffer_rsrc_t rs, char* lds, uns
 
 // 4-wave split-K kernel for fp32-accumulating launches (weight gradients), gemm_wgrad.hip
 int launch_w4s(hipStream_t st, const GemmParams& p, int ta, int tb);
-// 4-wave half of the ping-pong kernel, two workgroups per CU, gemm_solo.hip; -1: no instantiation for this launch
-int launch_solo(hipStream_t st, const GemmParams& p, int ta, int tb, int n_cus);
 // 4-wave 8-bit kernel on the 16x16x128 block MFMA, gemm_f8.hip; -1: no instantiation for this (format, epilogue, shape)
 int launch_f8_w4(hipStream_t st, const GemmParams& p, int a_format, int n_cus);
 

@@ -53,8 +53,6 @@ static void read_switches() {
   str("MDT_GEMM_TILE", g_sw.gemm_tile, sizeof(g_sw.gemm_tile));
   g_sw.gemm_no_pp = flag("MDT_GEMM_NO_PP");
   g_sw.gemm_w4 = num("MDT_GEMM_W4", 2);
-  g_sw.gemm_solo = num("MDT_GEMM_SOLO", 0);
-  g_sw.gemm_solo_skew = num("MDT_GEMM_SOLO_SKEW", -1);
   g_sw.gemm_f8w = num("MDT_GEMM_F8W", 1);
   g_sw.attn_v1 = flag("MDT_ATTN_V1");
   str("MDT_ATTN_BWD", g_sw.attn_bwd, sizeof(g_sw.attn_bwd));
