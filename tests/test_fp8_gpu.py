@@ -329,15 +329,23 @@ def test_fp8_producer_quantised_operands_equal_stand_alone_passes(monkeypatch):
     print(f"[fp8 fused vs stand-alone] logits sums {float(lg_f.double().sum()):.10f} / {float(lg_s.double().sum()):.10f}, max |diff| {float((lg_f - lg_s).abs().max()):.3e}, "
           f"first rows {lg_f[0].tolist()} / {lg_s[0].tolist()}")
     if not torch.equal(lg_f, lg_s):
-        # seen on SOME devices of the pool only: say which launch of a training step does not repeat itself there
+        # Seen on SOME devices of the pool only (DESIGN.md §4 "Still open"): there ONE route does not repeat its own result either.
+        # Tell the two cases apart: a route that repeats itself and differs from the other one is a bug of the fused producers
+        # (fail); a device on which the same route gives two answers is the open issue (xfail, with the launch that did not repeat).
         import os
         import subprocess
         import sys
+        lg_f2, _, _, _ = run(True)
+        lg_s2, _, _, _ = run(False)
+        repeats = torch.equal(lg_f2, lg_f) and torch.equal(lg_s2, lg_s)
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         tr = subprocess.run([sys.executable, os.path.join(root, "tools", "op_trace.py"), "4"], capture_output=True, text=True, timeout=600)
         lines = [ln for ln in tr.stdout.splitlines() if ln.startswith("repetition") or "SUSPICIOUS" in ln]
-        pytest.fail("fused and stand-alone routes differ (max |diff| %.3e); tools/op_trace.py on this device:\n%s" %
-                    (float((lg_f - lg_s).abs().max()), "\n".join(lines)[:4000]))
+        msg = ("fused and stand-alone routes differ (max |diff| %.3e); each route repeats itself: %s; tools/op_trace.py on this device:\n%s" %
+               (float((lg_f - lg_s).abs().max()), repeats, "\n".join(lines)[:4000]))
+        if repeats:
+            pytest.fail(msg)
+        pytest.xfail("this device does not repeat ONE fp8 route's own result (open issue, DESIGN.md §4): " + msg)
     # gradients: the split-K weight gradients add their slabs with fp32 atomics in whatever order they finish — equal up to that
     assert float((g_f.double() - g_s.double()).norm() / g_s.double().norm()) < 1e-5
 
