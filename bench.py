@@ -648,7 +648,9 @@ def main():
             mark("forward+loss")
             mark("backward")
         mark("scalars")
-        gscale = dp.finish_backward(scal, fold_scale=opt is not None)     # 1 / sample size rides on Adam's read of the gradients
+        # 1 / (global sample size) rides on the optimiser's read of the gradients (train.py; FairSeq applies it in the update phase,
+        # trainer.train_step's multiply_grads, not in the task's forward + backward): the step hands back the device scalar
+        gscale = dp.finish_backward(scal, fold_scale=True)
         if opt is not None:
             opt.step(grad_scale=gscale)
         mark("finish")
@@ -821,7 +823,7 @@ def main():
                                       if pf is not None else "two pre-packed HBM-resident batches alternate, ")
                                    + (f"a step = one update of {uf} micro-batches (--update-freq {uf}), " if uf > 1 else "")
                                    + ("frozen pre-fusion encoders (no adjoint, counted once in the FLOPs), " if frozen else "")
-                                   + ("fused Adam step included" if opt is not None else "no optimizer step (metric: fwd+bwd)"),
+                                   + ("fused Adam step included" if opt is not None else "no optimizer step (metric: fwd+bwd; the gradients' 1/sample-size factor is returned as a device scalar for the optimiser's read, as train.py does)"),
                        "name": args.config, "trees_per_gpu": args.trees, "comments_per_step_per_gpu": round(n_com, 1),
                        "parallelism": f"dp{world}", "frozen_initial_encoders": bool(args.freeze_initial_encoders)},
             "ms_per_step_median": round(ms_median, 2),

@@ -157,13 +157,12 @@ def attention_fwd(qkv, nseq, S, H, *, seq_stride=None, pos_stride=1, scale=None,
     the kernels that fit its cap; results are identical to the single launch."""
     D = qkv.shape[1] // 3
     hd = D // H
-    if q_limit:
-        # rows the kernel may skip must still read as "no contribution" for any backward kernel: out = 0, lse = +inf
-        out = torch.zeros(qkv.shape[0], D, dtype=qkv.dtype, device=qkv.device)
-        lse = torch.full((nseq, H, S), float("inf"), dtype=torch.float32, device=qkv.device)
-    else:
-        out = torch.empty(qkv.shape[0], D, dtype=qkv.dtype, device=qkv.device)   # every row belongs to a sequence
-        lse = torch.empty(nseq, H, S, dtype=torch.float32, device=qkv.device)
+    # No fill, also with q_limit: the kernels that honour it (bf16, head dim 64) write whole 16-row query tiles, and the backward
+    # kernels dispatched for such a launch read exactly those rows of out / lse and nothing past them
+    # (tests/test_kernels_gpu.py::test_attention_backward_never_reads_what_forward_did_not_write); every other kernel family ignores
+    # q_limit and writes all rows.  Positions of lse past a ragged sequence's length are never read either.
+    out = torch.empty(qkv.shape[0], D, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(nseq, H, S, dtype=torch.float32, device=qkv.device)
     if bins is not None and (qkv.dtype != torch.bfloat16 or hd != 64 or S > 272):
         bins = None                      # the binned launches exist for the bf16 head-dim-64 kernels only
     for ids, cap in (bins or [(None, 0)]):
@@ -210,8 +209,10 @@ def attention_bwd(dout, qkv, out, lse, nseq, S, H, *, seq_stride=None, pos_strid
                   bins=None):
     D = qkv.shape[1] // 3
     hd = D // H
-    # with q_limit the kernels skip the query rows beyond it: their dQ must read as zero
-    dqkv = torch.zeros_like(qkv) if q_limit else torch.empty_like(qkv)
+    # with q_limit the kernels skip the query rows beyond it: their dQ must read as zero (dK / dV are written for every row)
+    dqkv = torch.empty_like(qkv)
+    if q_limit:
+        dqkv[:, :D].zero_()
     dbias = None
     if want_dense_dbias:
         dbias = torch.zeros(nseq, H, S, S, dtype=torch.float32, device=qkv.device)

@@ -837,14 +837,26 @@ def test_attention_backward_never_reads_what_forward_did_not_write(ops, route, S
     vq = dev(valid_q)[:, None, :].expand(nseq, H, Smax)
     live = dev(row_live)[:, None]
     res = []
+    real_empty_like = torch.empty_like
     for poison in (float("nan"), float("inf"), -1e30, 0.0):
         lse_p = torch.where(vq, lse, torch.full_like(lse, poison))
         out_p = torch.where(live, out, torch.full_like(out, poison))
+        # the gradient buffer the wrapper allocates starts out as the same poison: whatever backward does not write shows
+        monkeypatch.setattr(torch, "empty_like", lambda t, *a, **k: real_empty_like(t, *a, **k).fill_(poison) if t.is_floating_point() else real_empty_like(t, *a, **k))
         dq, _ = ops.attention_bwd(dout, qkv, out_p, lse_p, nseq, Smax, H, **kw)
+        monkeypatch.setattr(torch, "empty_like", real_empty_like)
         assert bool(torch.isfinite(dq.float()).all()), poison
         res.append(dq)
     for r in res[1:]:
         assert torch.equal(r, res[0])
+    # ... and forward leaves nothing unwritten that anybody reads: the same forward into poisoned buffers gives the same gradients
+    real_empty = torch.empty
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **k).fill_(float("nan")) if k.get("dtype", torch.float32).is_floating_point else real_empty(*a, **k))
+    out_n, lse_n = ops.attention_fwd(qkv, nseq, Smax, H, **kw)
+    monkeypatch.setattr(torch, "empty", real_empty)
+    dq_n, _ = ops.attention_bwd(dout, qkv, out_n, lse_n, nseq, Smax, H, **kw)
+    assert torch.equal(dq_n, res[0])
+    assert torch.equal(out_n[dev(row_live)], out[dev(row_live)])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
