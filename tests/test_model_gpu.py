@@ -242,6 +242,74 @@ def test_full_model_fp32_vs_reference_golden_and_oracle(golden_dir, kind, ragged
         assert float((gr.float().cpu() - ref).abs().max()) <= tol, name
 
 
+@pytest.mark.parametrize("case", ["single_comment_trees", "no_images", "every_comment_an_image", "one_token_texts", "chains_and_stars"])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_edge_case_batches_vs_oracle_fp32(case, ragged):
+    """The shapes the reference's collator has to cope with and the kernels' index arithmetic has corners for — trees of ONE
+    comment (a graph of the graph token and one node), a batch without any image (the image branch never launches), a batch in
+    which every comment carries one, texts of a single valid token ([CLS] alone: one-row attention, one-row LayerNorm statistics
+    over a ragged batch), deep chains next to flat stars (spatial positions up to the clamp, degree 0 ... N - 1) — each against the
+    oracle on the same seeded inputs: logits, loss, counters and every parameter gradient at the 1e-3 gate."""
+    from multimodaldiscussiontransformer_amd import synthetic
+    from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
+    from multimodaldiscussiontransformer_amd.data.packer import pack_batch
+    from multimodaldiscussiontransformer_amd.models import GraphormerModel
+    from tests.util_model import split_qkv_grad
+    hp = cases.tiny_hparams("A")
+    kw = dict(seq_len=24, vocab_size=hp.vocab_size, image_size=hp.image_size, min_len=2)
+    rng = np.random.Generator(np.random.PCG64(99))
+    mk = lambda n, **k: synthetic.make_tree(n, rng, **{**kw, **k})
+    if case == "single_comment_trees":
+        trees = [mk(1), mk(1, image_frac=1.0), mk(5, image_frac=0.4), mk(1)]
+    elif case == "no_images":
+        trees = [mk(4), mk(7), mk(2)]
+    elif case == "every_comment_an_image":
+        trees = [mk(3, image_frac=1.0), mk(5, image_frac=1.0)]
+    elif case == "one_token_texts":
+        trees = [mk(6, image_frac=0.34), mk(3)]
+        for t in trees:                                  # [CLS] alone on most comments, two tokens on one
+            t["attention_mask"][:] = 0
+            t["attention_mask"][:, 0] = 1
+            t["attention_mask"][-1, 1] = 1
+            t["input_ids"] = t["input_ids"] * t["attention_mask"]
+    else:
+        chain = mk(9, image_frac=0.2)
+        chain["parent"] = np.arange(9, dtype=np.int64) - 1           # a thread 9 deep: spatial positions beyond the clamp of 5
+        star = mk(8, image_frac=0.25)
+        star["parent"] = np.array([-1] + [0] * 7, dtype=np.int64)    # everybody answers the post
+        trees = [chain, star, mk(2)]
+    model = GraphormerModel.build_model(model_args(hp), task=None)
+    fill_hash_weights(model)
+    model = model.cuda().eval()
+    model.encoder.graph_encoder.ragged_tokens = ragged
+    pb = pack_batch(trees, 5)
+    crit = GraphPredictionNodeCrossEntropy(None, positive_weight=hp.pos_weight, negative_weight=hp.neg_weight)
+    loss, sample_size, log = crit(model, {"nsamples": len(trees), "net_input": {"batched_data": pb.batched_data}})
+    loss.backward()
+    with torch.no_grad():
+        logits, _ = model(pb.batched_data)
+    ref_b = S.collate(trees, 5)
+    W = R.make_weights(hp)
+    batch = R.to_torch_batch(ref_b)
+    lo, _ = R.model_forward(W, hp, batch)
+    ol, olog = R.node_cross_entropy(lo, batch["y"], batch["y_mask"], hp)
+    ol.backward()
+    assert bool(torch.isfinite(logits).all()) and bool(torch.isfinite(lo).all())
+    np.testing.assert_allclose(logits.cpu().numpy(), lo.detach().numpy(), atol=1e-3)
+    assert abs(float(loss) - float(ol)) <= 2e-2 * max(1.0, abs(float(ol)))
+    grads = {n: q.grad for n, q in named_canonical_params(model).items()}
+    checked = 0
+    for name in W:
+        if W[name].grad is None:
+            continue
+        gr = split_qkv_grad(name, grads)
+        assert gr is not None, name
+        ref = W[name].grad
+        assert float((gr.float().cpu() - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max())), name
+        checked += 1
+    assert checked >= 90, checked            # without images the ViT side has no gradient (97 tensors), otherwise 150+
+
+
 def test_ragged_tokens_equal_padded_tokens_fp32():
     """Same weights, same batch (random comment lengths, one mask with a hole): logits, loss and every parameter
     gradient of the ragged layout equal the padded layout's to fp32 round-off."""
