@@ -242,46 +242,57 @@ def test_full_model_fp32_vs_reference_golden_and_oracle(golden_dir, kind, ragged
         assert float((gr.float().cpu() - ref).abs().max()) <= tol, name
 
 
-@pytest.mark.parametrize("case", ["single_comment_trees", "no_images", "every_comment_an_image", "one_token_texts", "chains_and_stars"])
-@pytest.mark.parametrize("ragged", [False, True])
-def test_edge_case_batches_vs_oracle_fp32(case, ragged):
-    """The shapes the reference's collator has to cope with and the kernels' index arithmetic has corners for — trees of ONE
-    comment (a graph of the graph token and one node), a batch without any image (the image branch never launches), a batch in
-    which every comment carries one, texts of a single valid token ([CLS] alone: one-row attention, one-row LayerNorm statistics
-    over a ragged batch), deep chains next to flat stars (spatial positions up to the clamp, degree 0 ... N - 1) — each against the
-    oracle on the same seeded inputs: logits, loss, counters and every parameter gradient at the 1e-3 gate."""
+EDGE_CASES = ["single_comment_trees", "no_images", "every_comment_an_image", "one_token_texts", "chains_and_stars"]
+
+
+def _edge_trees(case, hp):
     from multimodaldiscussiontransformer_amd import synthetic
-    from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
-    from multimodaldiscussiontransformer_amd.data.packer import pack_batch
-    from multimodaldiscussiontransformer_amd.models import GraphormerModel
-    from tests.util_model import split_qkv_grad
-    hp = cases.tiny_hparams("A")
     kw = dict(seq_len=24, vocab_size=hp.vocab_size, image_size=hp.image_size, min_len=2)
     rng = np.random.Generator(np.random.PCG64(99))
     mk = lambda n, **k: synthetic.make_tree(n, rng, **{**kw, **k})
     if case == "single_comment_trees":
-        trees = [mk(1), mk(1, image_frac=1.0), mk(5, image_frac=0.4), mk(1)]
-    elif case == "no_images":
-        trees = [mk(4), mk(7), mk(2)]
-    elif case == "every_comment_an_image":
-        trees = [mk(3, image_frac=1.0), mk(5, image_frac=1.0)]
-    elif case == "one_token_texts":
+        return [mk(1), mk(1, image_frac=1.0), mk(5, image_frac=0.4), mk(1)]
+    if case == "no_images":
+        return [mk(4), mk(7), mk(2)]
+    if case == "every_comment_an_image":
+        return [mk(3, image_frac=1.0), mk(5, image_frac=1.0)]
+    if case == "one_token_texts":
         trees = [mk(6, image_frac=0.34), mk(3)]
         for t in trees:                                  # [CLS] alone on most comments, two tokens on one
             t["attention_mask"][:] = 0
             t["attention_mask"][:, 0] = 1
             t["attention_mask"][-1, 1] = 1
             t["input_ids"] = t["input_ids"] * t["attention_mask"]
-    else:
-        chain = mk(9, image_frac=0.2)
-        chain["parent"] = np.arange(9, dtype=np.int64) - 1           # a thread 9 deep: spatial positions beyond the clamp of 5
-        star = mk(8, image_frac=0.25)
-        star["parent"] = np.array([-1] + [0] * 7, dtype=np.int64)    # everybody answers the post
-        trees = [chain, star, mk(2)]
+        return trees
+    chain = mk(9, image_frac=0.2)
+    chain["parent"] = np.arange(9, dtype=np.int64) - 1           # a thread 9 deep: spatial positions beyond the clamp of 5
+    star = mk(8, image_frac=0.25)
+    star["parent"] = np.array([-1] + [0] * 7, dtype=np.int64)    # everybody answers the post
+    return [chain, star, mk(2)]
+
+
+@pytest.mark.parametrize("case", EDGE_CASES)
+@pytest.mark.parametrize("mode", ["fp32-padded", "fp32-ragged", "bf16-ragged"])
+def test_edge_case_batches_vs_oracle(case, mode):
+    """The shapes the reference's collator has to cope with and the kernels' index arithmetic has corners for — trees of ONE
+    comment (a graph of the graph token and one node), a batch without any image (the image branch never launches), a batch in
+    which every comment carries one, texts of a single valid token ([CLS] alone: one-row attention, one-row LayerNorm statistics
+    over a ragged batch), deep chains next to flat stars (spatial positions up to the clamp, degree 0 ... N - 1) — each against the
+    oracle on the same seeded inputs.  fp32 (padded and ragged layouts): logits, loss and every parameter gradient at the 1e-3
+    gate.  bf16 (the production kernels: MFMA GEMMs, register-resident attention, one-pass backward on one-token rows): finite,
+    logits within 5e-2, all gradients together within 5e-2 relative L2 of the fp32 oracle."""
+    from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
+    from multimodaldiscussiontransformer_amd.data.packer import pack_batch
+    from multimodaldiscussiontransformer_amd.models import GraphormerModel
+    from tests.util_model import split_qkv_grad
+    hp = cases.tiny_hparams("A")
+    trees = _edge_trees(case, hp)
+    half = mode.startswith("bf16")
     model = GraphormerModel.build_model(model_args(hp), task=None)
     fill_hash_weights(model)
-    model = model.cuda().eval()
-    model.encoder.graph_encoder.ragged_tokens = ragged
+    model = model.cuda()
+    model = (model.bfloat16() if half else model).eval()
+    model.encoder.graph_encoder.ragged_tokens = mode.endswith("ragged")
     pb = pack_batch(trees, 5)
     crit = GraphPredictionNodeCrossEntropy(None, positive_weight=hp.pos_weight, negative_weight=hp.neg_weight)
     loss, sample_size, log = crit(model, {"nsamples": len(trees), "net_input": {"batched_data": pb.batched_data}})
@@ -295,19 +306,26 @@ def test_edge_case_batches_vs_oracle_fp32(case, ragged):
     ol, olog = R.node_cross_entropy(lo, batch["y"], batch["y_mask"], hp)
     ol.backward()
     assert bool(torch.isfinite(logits).all()) and bool(torch.isfinite(lo).all())
-    np.testing.assert_allclose(logits.cpu().numpy(), lo.detach().numpy(), atol=1e-3)
-    assert abs(float(loss) - float(ol)) <= 2e-2 * max(1.0, abs(float(ol)))
+    np.testing.assert_allclose(logits.float().cpu().numpy(), lo.detach().numpy(), atol=5e-2 if half else 1e-3)
+    assert abs(float(loss.detach()) - float(ol.detach())) <= (5e-2 if half else 2e-2) * max(1.0, abs(float(ol.detach())))
     grads = {n: q.grad for n, q in named_canonical_params(model).items()}
-    checked = 0
+    checked, num, den = 0, 0.0, 0.0
     for name in W:
         if W[name].grad is None:
             continue
         gr = split_qkv_grad(name, grads)
         assert gr is not None, name
         ref = W[name].grad
-        assert float((gr.float().cpu() - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max())), name
+        assert bool(torch.isfinite(gr).all()), name
+        if half:
+            num += float((gr.double().cpu() - ref.double()).pow(2).sum())
+            den += float(ref.double().pow(2).sum())
+        else:
+            assert float((gr.float().cpu() - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max())), name
         checked += 1
     assert checked >= 90, checked            # without images the ViT side has no gradient (97 tensors), otherwise 150+
+    if half:
+        assert (num / den) ** 0.5 <= 5e-2, (num / den) ** 0.5
 
 
 def test_ragged_tokens_equal_padded_tokens_fp32():
