@@ -1705,9 +1705,9 @@ extern "C" int mdt_gemm_fp8_q8(void* stream, int a_format, int64_t M, int64_t N,
 
 extern "C" int mdt_colsum(void* stream, int dtype, int64_t M, int64_t N, const void* X, int64_t ldx, float* out,
                           const int32_t* row_weight) {
-  MDT_CHECK_ARG(X && out, "mdt_colsum: null pointer");
   MDT_CHECK_ARG(dtype == MDT_F32 || dtype == MDT_BF16, "mdt_colsum: dtype %d", dtype);
-  if (M == 0 || N == 0) return MDT_OK;
+  if (M == 0 || N == 0) return MDT_OK;           // nothing to add (an empty X has no address)
+  MDT_CHECK_ARG(X && out, "mdt_colsum: null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int vn = dtype == MDT_BF16 ? 8 : 4;
   if (N % vn == 0 && ldx % vn == 0 && ((uintptr_t)X & 15) == 0) {

@@ -347,6 +347,44 @@ def test_colsum_cast_transpose(ops):
     assert torch.equal(ops.transpose2d(dev(x), torch.bfloat16).cpu(), xb.t().contiguous())
 
 
+def test_empty_inputs_are_no_ops(ops):
+    """A batch may carry no image, a rank no labelled comment, a length bin no sequence: every entry point the step calls takes
+    zero rows / sequences / images as a no-op (MDT_OK, nothing launched, outputs of the right — empty — shape)."""
+    bf = torch.bfloat16
+    D = 128
+    z = lambda *shape, dtype=bf: torch.empty(*shape, dtype=dtype, device="cuda")
+    w, b = dev(rnd(D, D, seed=1).to(bf)), dev(rnd(D, seed=2).to(bf))
+    assert ops.gemm(z(0, D), w, bias=b).shape == (0, D)
+    y, mean, rstd = ops.layernorm_fwd(z(0, D), b, b, 1e-5)
+    assert y.shape == (0, D) and mean.numel() == 0
+    dg = torch.zeros(D, dtype=torch.float32, device="cuda")
+    assert ops.layernorm_bwd(z(0, D), z(0, D), b, mean, rstd, dgamma=dg, dbeta=dg.clone()).shape == (0, D)
+    assert float(dg.abs().max()) == 0.0
+    out, lse = ops.attention_fwd(z(0, 3 * D), 0, 16, 2)
+    assert out.shape == (0, D)
+    dq, _ = ops.attention_bwd(z(0, D), z(0, 3 * D), out, lse, 0, 16, 2)
+    assert dq.shape == (0, 3 * D)
+    off = dev(torch.zeros(1, dtype=torch.int32))
+    out, lse = ops.attention_fwd(z(0, 3 * D), 0, 16, 2, seq_offsets=off)
+    assert out.shape == (0, D)
+    i32 = lambda n: torch.zeros(n, dtype=torch.int32, device="cuda")
+    word = dev(rnd(10, D, seed=3).to(bf))
+    ops.bert_embed_rows(i32(0), i32(0), i32(0), word, word, word[:2], z(0, D))
+    y, _, _, xs = ops.bert_embed_ln_rows(i32(0), i32(0), i32(0), word, word, word[:2], b, b, 1e-5)
+    assert y.shape == (0, D) and xs.shape == (0, D)
+    tok = z(0, 768)
+    ops.vit_patch_embed(torch.empty(0, 3, 32, 32, device="cuda"), 16, dev(rnd(768, 768, seed=4).to(bf)), dev(rnd(768, seed=5).to(bf)),
+                        dev(rnd(768, seed=6).to(bf)), dev(rnd(5, 768, seed=7).to(bf)), tok, seq_stride=5, off=0)
+    assert ops.vit_patchify(torch.empty(0, 3, 32, 32, device="cuda"), 16, bf).shape == (0, 768)
+    ops.row_axpby(z(4, D), 0, a=z(0, D))
+    table = torch.zeros(10, D, dtype=torch.float32, device="cuda")
+    ops.row_scatter_add(table, i32(0), z(0, D), 0)
+    assert float(table.abs().max()) == 0.0
+    assert ops.dropout(z(0, D), 0.3, 7).shape == (0, D)
+    assert ops.colsum(z(0, D)).shape == (D,) and float(ops.colsum(z(0, D)).abs().max()) == 0.0
+    torch.cuda.synchronize()
+
+
 # ----------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("D", [128, 768, 1024])
