@@ -328,6 +328,34 @@ def test_edge_case_batches_vs_oracle(case, mode):
         assert (num / den) ** 0.5 <= 5e-2, (num / den) ** 0.5
 
 
+@pytest.mark.parametrize("half", [False, True])
+def test_batch_without_a_labelled_comment(half):
+    """criterions/hatespeech_loss.py:95-118 on an empty selection: the summed cross-entropy of no logits is 0, sample_size 0, every
+    counter 0 — and backward runs (a data-parallel rank may draw such a batch while its peers do not): finite, all-zero gradients."""
+    from multimodaldiscussiontransformer_amd.criterions import GraphPredictionNodeCrossEntropy
+    from multimodaldiscussiontransformer_amd.data.packer import pack_batch
+    from multimodaldiscussiontransformer_amd.models import GraphormerModel
+    hp = cases.tiny_hparams("A")
+    trees = _edge_trees("chains_and_stars", hp)
+    for t in trees:
+        t["y_mask"][:] = False
+        t["y"] = np.zeros(0, dtype=np.float32)
+    model = GraphormerModel.build_model(model_args(hp), task=None)
+    fill_hash_weights(model)
+    model = model.cuda()
+    model = (model.bfloat16() if half else model).train()
+    pb = pack_batch(trees, 5)
+    crit = GraphPredictionNodeCrossEntropy(None, positive_weight=hp.pos_weight, negative_weight=hp.neg_weight)
+    loss, sample_size, log = crit(model, {"nsamples": len(trees), "net_input": {"batched_data": pb.batched_data}})
+    assert sample_size == 0 and float(loss.detach()) == 0.0
+    for k in ("ncorrect", "num_positive_correct", "total_positive", "num_pred_positive"):
+        assert int(log[k]) == 0, k
+    loss.backward()
+    for n, q in model.named_parameters():
+        if q.grad is not None:
+            assert bool(torch.isfinite(q.grad).all()) and float(q.grad.abs().max()) == 0.0, n
+
+
 def test_ragged_tokens_equal_padded_tokens_fp32():
     """Same weights, same batch (random comment lengths, one mask with a hole): logits, loss and every parameter
     gradient of the ragged layout equal the padded layout's to fp32 round-off."""
