@@ -323,7 +323,8 @@ def test_exchange_self_check_gloo_world2():
         assert status == "ok", f"rank {rank}: {info}"
 
 
-def test_bench_gpus_n_as_typed_starts_n_ranks():
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_gpus_n_as_typed_starts_n_ranks(n):
     """`python3 bench.py --gpus N` — the form the driver's N = 1 line uses, typed with N > 1 and no RANK in the environment —
     must start its own ranks (a fresh torch.distributed.run child, bench._self_launch) instead of asking to be launched.
     MDT_BENCH_LAUNCH_ONLY=1 stops every rank after the process group has counted itself (no GPU here)."""
@@ -332,13 +333,15 @@ def test_bench_gpus_n_as_typed_starts_n_ranks():
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env["MDT_BENCH_LAUNCH_ONLY"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env, cwd=ROOT,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1"], env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["distributed"]["world_seen_by_backend"] == 2 and out["steps"] == 3
+    assert out["n_gpus"] == n and out["distributed"]["world_seen_by_backend"] == n and out["steps"] == 3
+    if n != 2:
+        return
     # a failing rank's exit code comes back through the launcher
     env["MDT_BENCH_LAUNCH_ONLY"] = "0"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus=2", "--config", "nonsense"], env=env, cwd=ROOT, capture_output=True,
