@@ -172,8 +172,9 @@ typedef struct {
                                  dropout counters.  This is how padded token positions of a comment batch are never computed. */
   int q_limit;                /* 0 = every query row.  n > 0: only the first n rows of each sequence are needed as QUERIES
                                  (keys / values are always the whole sequence): forward leaves `out` / `lse` of the other rows
-                                 unspecified, backward assumes their `dout` is zero and returns dQ = 0 for them.  Kernels may
-                                 round n up (they work in 16-row tiles) or ignore it. */
+                                 unwritten (backward never reads them), backward assumes their `dout` is zero and does not
+                                 write their dQ — the caller zeroes the dQ third of dqkv beforehand; dK / dV are written for
+                                 every row.  Kernels may round n up (they work in 16-row tiles) or ignore it. */
   const int32_t* seq_ids;     /* NULL, or i32[nseq] (ragged bf16 launches only): this launch covers the sequences
                                  seq_ids[0 .. nseq) of a ragged set of `nseq_total` sequences — seq_offsets has nseq_total + 1
                                  entries, lse is [nseq_total, H, S] and the dropout counters use the sequence's own index, so a
