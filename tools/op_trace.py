@@ -5,7 +5,8 @@ by more than what fp32 atomics explain, whether their inputs still agreed (suspi
 the call (unwritten rows a later call fills), and where in the tensor the difference sits.
 --poison: fresh allocations are filled with 0 in repetition 0 and with NaN / 1e30 / -1e30 / 65504 in the later ones — a launch that reads a
 buffer nobody wrote differs on EVERY device then.
-GPU box only:  python tools/op_trace.py [reps] [--bf16] [--alone] [--one-stream] [--poison]"""
+--steps=N: N consecutive training steps per repetition (the fp8 model's producer-quantised operands start at its second step).
+GPU box only:  python tools/op_trace.py [reps] [--bf16] [--alone] [--one-stream] [--poison] [--steps=N]"""
 import os
 import sys
 
@@ -135,7 +136,7 @@ class Tracer:
                 return
 
 
-def run(tr, bf16, fused, one_stream, trace):
+def run(tr, bf16, fused, one_stream, trace, steps=1):
     fname, hp, trees, over = full_case("C2")
     fp8.FUSED_Q = fused
     torch.manual_seed(11)
@@ -149,12 +150,13 @@ def run(tr, bf16, fused, one_stream, trace):
     try:
         pb = pack_batch(trees, 5)
         crit = GraphPredictionNodeCrossEntropy(None, positive_weight=hp.pos_weight, negative_weight=hp.neg_weight)
-        torch.manual_seed(100)
-        model.zero_main_grads()
         torch.cuda.synchronize()
         tr.recording, tr.idx = trace, 0
-        loss, n, log = crit(model, {"nsamples": len(trees), "net_input": {"batched_data": pb.batched_data}})
-        loss.backward()
+        for step in range(steps):                      # later steps of the fp8 model run the producer-quantised (fused) operands
+            torch.manual_seed(100 + step)
+            model.zero_main_grads()
+            loss, n, log = crit(model, {"nsamples": len(trees), "net_input": {"batched_data": pb.batched_data}})
+            loss.backward()
         torch.cuda.synchronize()
         tr.recording = False
         return float(loss), model.main_grad_flat.clone(), (st.scale[:len(st.sites)].clone() if st is not None else None)
@@ -197,10 +199,11 @@ def main():
         if callable(fn) and not isinstance(fn, type):
             setattr(ops, name, tr.wrap(name, fn))
     poison = "--poison" in argv
+    steps = int(next((a.split("=")[1] for a in argv if a.startswith("--steps=")), "1"))
     fills = [0.0, float("nan"), 1e30, -1e30, 65504.0]
     if poison:
         poison_allocations(fills[0])
-    loss0, g0, s0 = run(tr, bf16, not alone, one_stream, True)
+    loss0, g0, s0 = run(tr, bf16, not alone, one_stream, True, steps)
     tr.ref, tr.cur = tr.cur, []
     print(f"repetition 0: {len(tr.ref)} traced calls, loss {loss0:.8f}, |g| {float(g0.norm()):.6f}", flush=True)
     for rep in range(1, reps):
@@ -208,7 +211,7 @@ def main():
         if poison:
             poison_allocations(fills[rep % len(fills)])
             print(f"   (fresh allocations filled with {fills[rep % len(fills)]})", flush=True)
-        loss, g, s = run(tr, bf16, not alone, one_stream, True)
+        loss, g, s = run(tr, bf16, not alone, one_stream, True, steps)
         gd = float((g - g0).norm() / g0.norm())
         sd = int((s != s0).sum()) if s is not None else 0
         print(f"repetition {rep}: loss d {loss - loss0:+.2e}, gradient rel-L2 {gd:.2e}, first scales differing {sd}; "
