@@ -296,11 +296,18 @@ def bert_embed_ln_rows(ids, types, pos_ids, word, pos, type_emb, gamma, beta, ep
     return y, mean, rstd, xs
 
 
-def vit_patchify(images, patch, dtype):
+def vit_patchify(images, patch, dtype, k_pad=0):
+    """``k_pad`` > C * patch^2: the gathered matrix gets zero columns up to that width (the MFMA tile GEMMs want K a multiple of
+    their k-step: ViT-L/14 has K = 588)."""
     I, Cc, HW, _ = images.shape
     assert images.dtype == torch.float32 and images.is_contiguous()
     g = HW // patch
-    cols = torch.empty(I * g * g, Cc * patch * patch, dtype=dtype, device=images.device)
+    k = Cc * patch * patch
+    if k_pad > k:
+        cols = torch.empty(I * g * g, k_pad, dtype=dtype, device=images.device)
+        cols[:, k:].zero_()
+    else:
+        cols = torch.empty(I * g * g, k, dtype=dtype, device=images.device)
     check(lib.mdt_vit_patchify(stream(), dt(cols), I, Cc, HW, patch, ptr(images), ptr(cols), _2d(cols)),
           "mdt_vit_patchify")
     return cols

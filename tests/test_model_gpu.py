@@ -685,6 +685,41 @@ def test_large_shaped_encoder_block_bf16(kind, S, nseq):
     assert cos > 0.99, cos
 
 
+@pytest.mark.parametrize("pad", [True, False])
+def test_patch_embedding_of_14_pixel_patches(monkeypatch, pad):
+    """ViT-L/14: Conv2d(3, D, k = s = 14) is a GEMM with K = 588 — not a multiple of the MFMA tile kernels' k-step.  The gathered
+    matrix and the weight are zero-padded to K = 640 (engine.vit_embeddings, engine.PATCH_K_PAD) so that the projection and its
+    weight gradient run on the tile kernels (mDT-large step: -3 ms in one call); MDT_PATCH_K_PAD=0 keeps the any-shape kernel.
+    Both against F.conv2d in fp32 on the bf16-rounded operands: tokens, and the gradients of weight, bias, [CLS] and positions."""
+    import torch.nn.functional as F
+    from multimodaldiscussiontransformer_amd import engine as E
+    monkeypatch.setattr(E, "PATCH_K_PAD", pad)
+    bf = torch.bfloat16
+    I, HW, P, D = 20, 56, 14, 256                  # 16 patches per image: 320 rows
+    npatch = (HW // P) ** 2
+    img = hu("pe/img", (I, 3, HW, HW), 2.0)
+    w = torch.nn.Parameter(hu("pe/w", (D, 3, P, P), 0.05).to(bf).cuda())
+    b = torch.nn.Parameter(hu("pe/b", (D,), 0.3).to(bf).cuda())
+    cls = torch.nn.Parameter(hu("pe/cls", (1, 1, D), 1.0).to(bf).cuda())
+    pos = torch.nn.Parameter(hu("pe/pos", (1, npatch + 1, D), 0.5).to(bf).cuda())
+    cot = hu("pe/cot", (I * (npatch + 1), D), 1.0).to(bf)
+
+    def run(tape):
+        return (E.vit_embeddings(tape, img.cuda(), w, b, cls, pos, P),)
+
+    (tok,) = E.run_tape(run, [], [w, b, cls, pos])
+    (tok.float() * cot.cuda().float()).sum().backward()
+    wr, br = w.detach().float().cpu().requires_grad_(True), b.detach().float().cpu().requires_grad_(True)
+    cr, pr = cls.detach().float().cpu().requires_grad_(True), pos.detach().float().cpu().requires_grad_(True)
+    conv = F.conv2d(img.to(bf).float(), wr, br, stride=P).flatten(2).transpose(1, 2)
+    ref = torch.cat([cr.expand(I, 1, D), conv], 1) + pr
+    (ref.reshape(-1, D) * cot.float()).sum().backward()
+    assert float((tok.detach().float().cpu() - ref.detach().reshape(-1, D)).abs().max()) <= 0.06          # values up to ~6, bf16 eps 0.4 % (two roundings)
+    for got, want, name in ((w.grad, wr.grad, "weight"), (b.grad, br.grad, "bias"), (cls.grad, cr.grad, "cls"), (pos.grad, pr.grad, "pos")):
+        rel = float((got.float().cpu() - want).norm() / want.norm())
+        assert rel <= 2e-2, (name, rel)
+
+
 def test_frozen_initial_encoders_stop_the_gradient_chain(monkeypatch):
     """--freeze_initial_encoders (run_train.sh:61): the reference's autograd never enters the frozen embeddings /
     pre-fusion layers.  Here too: no adjoint of the frozen prefix runs (counted by its GEMM launches), frozen parameters
